@@ -1,0 +1,141 @@
+/*
+ * als_hip.h - C ABI of the MI355X (gfx950) implicit-ALS engine, libals_hip.so.
+ *
+ * The reference (whong92/recommender, package reclibwh) has no native interface: its
+ * boundary for this path is a set of Python functions in reclibwh/core/ALS.py.  Every
+ * entry point below names the reference function it stands in for.  A host binds these
+ * with ctypes; signatures use plain pointers and sizes only.
+ *
+ * Conventions
+ *   - every pointer marked [device] is device memory owned by the caller; the library
+ *     never allocates or frees device memory and keeps no pointer after a call returns;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*, NULL = the null
+ *     stream); no call synchronises with the host;
+ *   - factors are float32 row-major with an explicit leading dimension (elements);
+ *     CSR is int64 row pointers, int32 column indices, float32 values;
+ *   - return value: ALS_OK or an error code; als_last_error_string() describes the
+ *     last error on the calling thread;
+ *   - results are bit-for-bit reproducible: no floating-point atomics, every reduction
+ *     has a fixed order that depends only on the inputs and on `chunk_nnz`, never on
+ *     the launch geometry, on timing, or on how rows are split across devices.
+ */
+#ifndef ALS_HIP_H
+#define ALS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALS_OK 0
+#define ALS_ERR_INVALID_ARG 1 /* null pointer, negative size, bad alignment, ...          */
+#define ALS_ERR_UNSUPPORTED 2 /* factor count outside the supported range                 */
+#define ALS_ERR_WORKSPACE 3   /* workspace smaller than the matching *_workspace_bytes()  */
+#define ALS_ERR_HIP 4         /* a HIP runtime call failed (message holds hipGetErrorString) */
+
+#define ALS_MAX_FACTORS 128         /* largest f the exact-solve path supports                 */
+#define ALS_DEFAULT_CHUNK_NNZ 2048  /* rows longer than this are split (multiple of 64)        */
+#define ALS_GRAM_CHUNK_ROWS 1024    /* rows per first-level Gram partial                       */
+#define ALS_GRAM_SUPER_ROWS 65536   /* rows per second-level Gram partial (64 chunks)          */
+
+/* Description of the last error on this thread ("" if none).  Replaces the Python
+ * exceptions / asserts of the reference (reclibwh/core/ALS.py:124,145). */
+const char *als_last_error_string(void);
+
+/* Library ABI version (bumped on any signature change). */
+int32_t als_abi_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Row schedule ("plan") - host-side, CPU only, built once per CSR matrix.
+ *
+ * Replaces the batching done by SparseMatRowIterator / get_pos_ratings_padded
+ * (reclibwh/data/iterators.py:160-193, reclibwh/utils/utils.py:142-173): instead of
+ * padded [B, Lmax] batches the device walks raw CSR rows.  A row with more than
+ * chunk_nnz stored entries is split into ceil(nnz/chunk_nnz) chunk items whose partial
+ * sums are combined in chunk order; items are sorted longest first.
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t row;    /* row of the CSR handed to als_half_sweep_csr_f32                      */
+    int32_t chunk;  /* -1: whole row, solved in place; >= 0: chunk index within a long row  */
+    int32_t slot;   /* partial-sum slot for a chunk item, -1 otherwise                      */
+    int32_t reserved;
+} als_item_t;
+
+typedef struct {
+    int32_t row;
+    int32_t first_slot; /* its chunks own slots first_slot .. first_slot + n_chunks - 1 */
+    int32_t n_chunks;
+    int32_t reserved;
+} als_long_row_t;
+
+/* Sizes of the plan for rows 0..n_rows-1 of rowptr_host (host memory, n_rows+1 entries). */
+int32_t als_plan_count(const int64_t *rowptr_host, int64_t n_rows, int32_t chunk_nnz, int64_t *n_items,
+                       int64_t *n_long, int64_t *n_slots);
+/* Fills items_host[n_items] and long_host[n_long] (host memory); upload them afterwards. */
+int32_t als_plan_fill(const int64_t *rowptr_host, int64_t n_rows, int32_t chunk_nnz, als_item_t *items_host,
+                      als_long_row_t *long_host);
+
+/* ------------------------------------------------------------------------------------
+ * Gram cache - replaces als_update_cache (reclibwh/core/ALS.py:235-246):
+ *     Y2 <- Y^T Y over all n rows of the layer;  LambdaI <- lamb * I.
+ *
+ * gram_out   [device] f*f floats, row major: Y^T Y (no lambda), exactly symmetric.
+ * tiles_out  [device] als_gram_tiles_bytes(f) bytes: Y^T Y + lamb*I in the register-tile
+ *            order the half-sweep kernel consumes (opaque to the caller).
+ * The sum over rows is a fixed three-level tree (1024-row chunks, 64-chunk groups, then
+ * the groups in order), so a Gram assembled from als_gram_partials_f32 calls on several
+ * devices equals the single-device one bit for bit.
+ * ------------------------------------------------------------------------------------ */
+size_t als_gram_tiles_bytes(int32_t f);
+size_t als_gram_workspace_bytes(int64_t n, int32_t f);
+int32_t als_gram_f32(const float *Y, int64_t n, int32_t f, int64_t ldy, float lamb, float *gram_out,
+                     float *tiles_out, void *workspace, size_t ws_bytes, void *stream);
+
+/* Second-level partials for rows [row_begin, row_end) of Y; row_begin must be a multiple
+ * of ALS_GRAM_SUPER_ROWS.  Writes ceil((row_end-row_begin)/ALS_GRAM_SUPER_ROWS) partials
+ * of als_gram_tiles_bytes(f) bytes each to super_out [device].  Workspace as for
+ * als_gram_workspace_bytes(row_end - row_begin, f).  (Multi-device Gram, no reference
+ * counterpart: the reference is single device.) */
+int32_t als_gram_partials_f32(const float *Y, int64_t row_begin, int64_t row_end, int32_t f, int64_t ldy,
+                              float *super_out, void *workspace, size_t ws_bytes, void *stream);
+/* Sums n_super second-level partials in order and emits gram_out / tiles_out as above. */
+int32_t als_gram_finalize_f32(const float *super_in, int64_t n_super, int32_t f, float lamb, float *gram_out,
+                              float *tiles_out, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Half-sweep - replaces run_als_epoch / run_als_step / als_run_regression
+ * (reclibwh/core/ALS.py:160-233) and ALSRef._run_single_step (ALS.py:67-88):
+ * for every row u of the CSR
+ *     A_u = Y^T Y + sum_j alpha r_uj y_j y_j^T + lamb I,   b_u = sum_j (1 + alpha r_uj) y_j
+ *     x_u = A_u^{-1} b_u            (Cholesky; the reference forms inv(A_u), ALS.py:82,172)
+ * X is updated in place (ALS.py:196-197) and *absdiff_out receives
+ * sum_u sum_k |x_u,k(old) - x_u,k(new)| (ALS.py:195), accumulated in double.
+ * Stored zeros contribute nothing (ALS.py:79); ratings are expected to be > 0.
+ * A row without entries gets x_u = 0.
+ *
+ * rowptr/col/val [device] CSR with n_rows rows; column indices must lie in [0, n_opp).
+ * row_ids        [device] optional: row u of the CSR updates X row row_ids[u] (fold-in,
+ *                ALS.py:387-395); NULL = identity.
+ * items/long_rows[device] the uploaded plan for this CSR (same chunk_nnz).
+ * Yopp           [device] the fixed factor, n_opp rows, leading dimension ldy.
+ * gram_tiles     [device] tiles_out of als_gram_f32 for Yopp (carries lamb).
+ * Xown           [device] the factor being solved for, leading dimension ldx.
+ * absdiff_out    [device] one double, or NULL.
+ * info_out       [device] one int32, or NULL: incremented once per row whose system
+ *                was not positive definite in float32 (that row's x is then NaN).
+ * ------------------------------------------------------------------------------------ */
+size_t als_half_sweep_workspace_bytes(int64_t n_rows, int64_t n_slots, int32_t f);
+int32_t als_half_sweep_csr_f32(const int64_t *rowptr, const int32_t *col, const float *val, int64_t n_rows,
+                               const int64_t *row_ids, const als_item_t *items, int64_t n_items,
+                               const als_long_row_t *long_rows, int64_t n_long, int64_t n_slots,
+                               int32_t chunk_nnz, const float *Yopp, int64_t n_opp, int64_t ldy,
+                               const float *gram_tiles, int32_t f, float alpha, float *Xown, int64_t ldx,
+                               double *absdiff_out, int32_t *info_out, void *workspace, size_t ws_bytes,
+                               void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALS_HIP_H */

@@ -1,0 +1,64 @@
+"""ctypes binding of libals_hip.so (the C ABI in include/als_hip.h).
+
+There is no fallback: if the shared library is missing or a symbol cannot be bound,
+importing this module raises.  Build it with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C recommender_amd/csrc`.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libals_hip.so")
+
+ALS_OK = 0
+ERROR_NAMES = {1: "invalid argument", 2: "unsupported", 3: "workspace too small", 4: "HIP error"}
+DEFAULT_CHUNK_NNZ = 2048
+GRAM_CHUNK_ROWS = 1024
+GRAM_SUPER_ROWS = 65536
+MAX_FACTORS = 128
+
+c_i32, c_i64, c_f32, c_sz, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol include/als_hip.h declares
+SIGNATURES = {
+    "als_last_error_string": (ctypes.c_char_p, []),
+    "als_abi_version": (c_i32, []),
+    "als_plan_count": (c_i32, [c_vp, c_i64, c_i32, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
+    "als_plan_fill": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp]),
+    "als_gram_tiles_bytes": (c_sz, [c_i32]),
+    "als_gram_workspace_bytes": (c_sz, [c_i64, c_i32]),
+    "als_gram_f32": (c_i32, [c_vp, c_i64, c_i32, c_i64, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "als_gram_partials_f32": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i64, c_vp, c_vp, c_sz, c_vp]),
+    "als_gram_finalize_f32": (c_i32, [c_vp, c_i64, c_i32, c_f32, c_vp, c_vp, c_vp]),
+    "als_half_sweep_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32]),
+    "als_half_sweep_csr_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32,
+                                       c_vp, c_i64, c_i64, c_vp, c_i32, c_f32, c_vp, c_i64, c_vp, c_vp, c_vp, c_sz,
+                                       c_vp]),
+}
+
+
+class AlsHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "recommender_amd: %s is missing - the HIP extension has not been built "
+            "(run __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    if rc != ALS_OK:
+        msg = lib.als_last_error_string().decode("utf-8", "replace")
+        exc = ValueError if rc in (1, 2, 3) else AlsHipError
+        raise exc("%s failed (%s): %s" % (what, ERROR_NAMES.get(rc, rc), msg))

@@ -1,0 +1,745 @@
+// libals_hip.so - hand-written gfx950 (MI355X, CDNA4) kernels for implicit ALS and the
+// C ABI declared in include/als_hip.h.
+//
+// Layout of one wavefront's work (all kernels use 64-thread workgroups = one wave):
+//
+//   A 16-lane group g = lane>>4 handles one gathered factor row per k-step, lane
+//   j = lane&15 of the group holds VW = FPAD/16 of its elements (one 16-byte load for
+//   FPAD = 64).  Those registers are directly the A and B operands of
+//   v_mfma_f32_16x16x4_f32 (A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15]), so the
+//   rank-4 update  sum_k w_k y_k y_k^T  of the f x f normal matrix is VW*(VW+1)/2 MFMAs
+//   per 4 gathered rows with no LDS staging and no cross-lane traffic.  Tile (ta, tb)
+//   element (i, j) is matrix element (fidx(i, ta), fidx(j, tb)); only tiles ta <= tb are
+//   computed (symmetry).
+//
+//   The MFMA is an exact k-ordered fp32 fma chain, rows are visited in CSR order, long
+//   rows are cut at fixed multiples of chunk_nnz and combined in chunk order: results
+//   do not depend on the launch geometry.
+//
+//   The f x f solve is a right-looking Cholesky with one matrix row per lane held in
+//   registers; pivots and multipliers are broadcast with v_readlane.  LDS is used only
+//   to move the matrix from the MFMA tile layout to the row-per-lane layout and to
+//   transpose L for the back substitution (packed lower triangle: conflict free).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "als_hip.h"
+
+namespace {
+
+// ----------------------------------------------------------------------------- errors
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define ALS_HIP_CHECK(expr)                                                                   \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(ALS_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ----------------------------------------------------------------------------- geometry
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int VW>
+struct Geo {
+    static constexpr int FPAD = 16 * VW;               // padded factor count
+    static constexpr int NT = VW * (VW + 1) / 2;       // symmetric 16x16 tiles
+    static constexpr int TQ = NT * 4;                  // tile floats per lane
+    static constexpr int PQ = NT * 4 + VW;             // floats per lane of a stored partial (tiles + b)
+    static constexpr int TRI = FPAD * (FPAD + 1) / 2;  // packed lower triangle
+};
+
+__host__ __device__ constexpr int tile_index(int ta, int tb, int VW) { return ta * VW - ta * (ta - 1) / 2 + (tb - ta); }
+
+// factor index held by lane j (0..15) of a group in its register t (0..VW-1)
+template <int VW>
+__host__ __device__ __forceinline__ constexpr int fidx(int j, int t) {
+    if constexpr (VW <= 4) return VW * j + t;
+    else return (t < 4) ? 4 * j + t : 64 + 4 * j + (t - 4);
+}
+
+constexpr int GS = 4;  // k-steps per pipeline stage (16 gathered rows)
+
+template <int VW>
+struct Stage {
+    float v[GS][VW];
+    float w[GS];
+    float cw[GS];
+};
+
+// ----------------------------------------------------------------------------- loads
+// Elements fidx(j, 0..VW-1) of the factor row at rowp; elements >= f read as 0.
+template <int VW, bool VEC>
+__device__ __forceinline__ void load_vec(const float *__restrict__ rowp, int f, int j, float (&v)[VW]) {
+    if constexpr (!VEC || VW == 1) {
+#pragma unroll
+        for (int t = 0; t < VW; ++t) {
+            const int idx = fidx<VW>(j, t);
+            const bool ok = idx < f;
+            const float x = rowp[ok ? idx : 0];
+            v[t] = ok ? x : 0.f;
+        }
+    } else if constexpr (VW == 2) {
+        const bool ok = 2 * j < f;
+        const f32x2 x = *reinterpret_cast<const f32x2 *>(rowp + (ok ? 2 * j : 0));
+        v[0] = ok ? x.x : 0.f;
+        v[1] = ok ? x.y : 0.f;
+    } else {
+#pragma unroll
+        for (int h = 0; h < VW / 4; ++h) {
+            const int idx = 64 * h + 4 * j;
+            const bool ok = idx < f;
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(rowp + (ok ? idx : 0));
+            v[4 * h + 0] = ok ? x.x : 0.f;
+            v[4 * h + 1] = ok ? x.y : 0.f;
+            v[4 * h + 2] = ok ? x.z : 0.f;
+            v[4 * h + 3] = ok ? x.w : 0.f;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- accumulate
+// Issue the gathers of group g (16 entries) of the 64-entry chunk whose column indices and
+// ratings sit one per lane in (cur_c, cur_r).
+template <int VW, bool VEC>
+__device__ __forceinline__ void issue(Stage<VW> &st, const int g, const int cur_c, const float cur_r,
+                                      const float *__restrict__ Y, const int64_t ld, const int f, const float alpha,
+                                      const int lane) {
+    const int grp = lane >> 4, j = lane & 15;
+#pragma unroll
+    for (int s = 0; s < GS; ++s) {
+        const int src = g * (GS * 4) + s * 4 + grp;
+        const int cj = __shfl(cur_c, src);
+        const float rj = __shfl(cur_r, src);
+        const float w = alpha * rj;
+        st.w[s] = w;
+        st.cw[s] = (rj != 0.f) ? 1.f + w : 0.f;
+        load_vec<VW, VEC>(Y + (int64_t)cj * ld, f, j, st.v[s]);
+    }
+}
+
+template <int VW, bool WITH_B>
+__device__ __forceinline__ void compute(const Stage<VW> &st, f32x4 (&acc)[Geo<VW>::NT], float (&bacc)[VW]) {
+#pragma unroll
+    for (int s = 0; s < GS; ++s) {
+#pragma unroll
+        for (int ta = 0; ta < VW; ++ta) {
+            const float a = st.w[s] * st.v[s][ta];
+#pragma unroll
+            for (int tb = ta; tb < VW; ++tb) {
+                const int t = tile_index(ta, tb, VW);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, st.v[s][tb], acc[t], 0, 0, 0);
+            }
+            if constexpr (WITH_B) bacc[ta] = fmaf(st.cw[s], st.v[s][ta], bacc[ta]);
+        }
+    }
+}
+
+// acc += sum_{e in [s, e)} w_e y_e y_e^T, bacc += sum c_e y_e over CSR entries [s, e) (GATHER)
+// or over the dense rows [s, e) of Y with w = 1 (!GATHER, the Gram).  s, e are wave uniform, e > s.
+template <int VW, bool VEC, bool GATHER>
+__device__ __forceinline__ void accumulate_range(f32x4 (&acc)[Geo<VW>::NT], float (&bacc)[VW],
+                                                 const int32_t *__restrict__ col, const float *__restrict__ val,
+                                                 const int64_t s, const int64_t e, const float *__restrict__ Y,
+                                                 const int64_t ld, const int f, const float alpha, const int lane) {
+    Stage<VW> A, B;
+    int cur_c, nxt_c = 0;
+    float cur_r, nxt_r = 0.f;
+    auto load_chunk = [&](const int64_t base, int &c, float &r) {
+        const int64_t idx = base + lane;
+        const bool ok = idx < e;
+        if constexpr (GATHER) {
+            const int64_t ii = ok ? idx : s;
+            const int cc = col[ii];
+            const float rr = val[ii];
+            c = ok ? cc : 0;
+            r = ok ? rr : 0.f;
+        } else {
+            c = ok ? (int)idx : 0;
+            r = ok ? 1.f : 0.f;
+        }
+    };
+    load_chunk(s, cur_c, cur_r);
+    issue<VW, VEC>(A, 0, cur_c, cur_r, Y, ld, f, alpha, lane);
+    for (int64_t base = s; base < e; base += 64) {
+        const int64_t nb = base + 64;
+        const bool more = nb < e;
+        if (more) load_chunk(nb, nxt_c, nxt_r);
+        const int rem = more ? 64 : (int)(e - base);
+        const int ng = (rem + 15) >> 4;
+        if (ng > 1) issue<VW, VEC>(B, 1, cur_c, cur_r, Y, ld, f, alpha, lane);
+        compute<VW, GATHER>(A, acc, bacc);
+        if (ng > 2) issue<VW, VEC>(A, 2, cur_c, cur_r, Y, ld, f, alpha, lane);
+        if (ng > 1) compute<VW, GATHER>(B, acc, bacc);
+        if (ng > 3) issue<VW, VEC>(B, 3, cur_c, cur_r, Y, ld, f, alpha, lane);
+        if (ng > 2) compute<VW, GATHER>(A, acc, bacc);
+        if (more) {
+            cur_c = nxt_c;
+            cur_r = nxt_r;
+            issue<VW, VEC>(A, 0, cur_c, cur_r, Y, ld, f, alpha, lane);
+        }
+        if (ng > 3) compute<VW, GATHER>(B, acc, bacc);
+    }
+}
+
+template <int VW>
+__device__ __forceinline__ void reduce_b(float (&bacc)[VW]) {
+    // the 4 lane groups hold partial sums of the same elements: fixed butterfly order
+#pragma unroll
+    for (int t = 0; t < VW; ++t) {
+        bacc[t] += __shfl_xor(bacc[t], 16);
+        bacc[t] += __shfl_xor(bacc[t], 32);
+    }
+}
+
+// ----------------------------------------------------------------------------- solve
+__device__ __forceinline__ float readlane_f(const float x, const int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
+}
+
+// Solve (acc + gram_tiles) x = b for one row (f <= 64) and write x.  `lds` is this wave's
+// private Geo<VW>::TRI + FPAD floats.  Returns |x_old - x_new| summed over the row in lane 0.
+template <int VW>
+__device__ __forceinline__ float solve_row(const f32x4 (&acc)[Geo<VW>::NT], const float (&bacc)[VW],
+                                           const float *__restrict__ gtiles, float *lds, const int f,
+                                           float *__restrict__ xrow, int32_t *info, const int lane) {
+    constexpr int FPAD = Geo<VW>::FPAD;
+    constexpr int TRI = Geo<VW>::TRI;
+    const int grp = lane >> 4, j = lane & 15;
+
+    // 1. tile layout -> packed lower triangle in LDS (each unordered index pair written once)
+#pragma unroll
+    for (int ta = 0; ta < VW; ++ta) {
+#pragma unroll
+        for (int tb = ta; tb < VW; ++tb) {
+            const int t = tile_index(ta, tb, VW);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = grp * 4 + r;
+                const int ai = fidx<VW>(i, ta), bi = fidx<VW>(j, tb);
+                const float v = acc[t][r] + gtiles[(t * 4 + r) * 64 + lane];
+                const int hi = max(ai, bi), lo = min(ai, bi);
+                if (ta != tb || i >= j) lds[hi * (hi + 1) / 2 + lo] = v;
+            }
+        }
+    }
+    if (grp == 0) {
+#pragma unroll
+        for (int t = 0; t < VW; ++t) lds[TRI + fidx<VW>(j, t)] = bacc[t];
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // 2. one matrix row per lane
+    const int ic = min(lane, FPAD - 1);
+    const int rowoff = ic * (ic + 1) / 2;
+    float a[FPAD];
+#pragma unroll
+    for (int jj = 0; jj < FPAD; ++jj) a[jj] = lds[rowoff + jj];
+    float bv = lds[TRI + ic];
+    __builtin_amdgcn_wave_barrier();
+
+    // 3. right-looking Cholesky fused with the forward substitution L z = b
+    float z = 0.f, myrinv = 0.f;
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < FPAD; ++k) {
+        if (k < f) {
+            const float akk = readlane_f(a[k], k);
+            bad = bad || !(akk > 0.f);
+            const float rinv = 1.0f / sqrtf(akk);
+            const float lik = a[k] * rinv;
+            a[k] = lik;
+            const float zk = readlane_f(bv, k) * rinv;
+            if (lane == k) {
+                myrinv = rinv;
+                z = zk;
+            }
+            bv = fmaf(-lik, zk, bv);  // meaningful for lanes > k only
+#pragma unroll
+            for (int jj = k + 1; jj < FPAD; ++jj) {
+                const float ljk = readlane_f(lik, jj);
+                a[jj] = fmaf(-lik, ljk, a[jj]);  // meaningful for lanes >= jj only
+            }
+        }
+    }
+
+    // 4. L -> LDS, read back transposed: u[k] = L[k][lane]
+#pragma unroll
+    for (int jj = 0; jj < FPAD; ++jj)
+        if (jj <= lane && lane < FPAD) lds[rowoff + jj] = a[jj];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int jj = 0; jj < FPAD; ++jj) a[jj] = lds[jj * (jj + 1) / 2 + ic];
+    __builtin_amdgcn_wave_barrier();
+
+    // 5. back substitution L^T x = z
+    float x = 0.f;
+#pragma unroll
+    for (int k = FPAD - 1; k >= 0; --k) {
+        if (k < f) {
+            const float xk = readlane_f(z, k) * readlane_f(myrinv, k);
+            if (lane == k) x = xk;
+            if (lane < k) z = fmaf(-a[k], xk, z);
+        }
+    }
+
+    // 6. write back, |delta|
+    float d = 0.f;
+    if (lane < f) {
+        d = fabsf(xrow[lane] - x);
+        xrow[lane] = x;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) d += __shfl_xor(d, o);
+    if (bad && lane == 0 && info) atomicAdd(info, 1);
+    return d;
+}
+
+// ----------------------------------------------------------------------------- kernels
+struct SweepParams {
+    const int64_t *rowptr;
+    const int32_t *col;
+    const float *val;
+    const int64_t *row_ids;
+    const als_item_t *items;
+    const als_long_row_t *long_rows;
+    const float *Y;
+    const float *gtiles;
+    float *X;
+    float *partials;
+    float *rowdiff;
+    int32_t *info;
+    int64_t ldy, ldx;
+    int32_t f, chunk_nnz;
+    float alpha;
+};
+
+template <int VW, bool VEC>
+__global__ __launch_bounds__(64) void sweep_items_kernel(const SweepParams p) {
+    using G = Geo<VW>;
+    __shared__ float lds[G::TRI + G::FPAD];
+    const int lane = threadIdx.x;
+    const als_item_t it = p.items[blockIdx.x];
+    const int row = it.row;
+    int64_t s = p.rowptr[row], e = p.rowptr[row + 1];
+    if (it.chunk >= 0) {
+        s += (int64_t)it.chunk * p.chunk_nnz;
+        e = min(e, s + (int64_t)p.chunk_nnz);
+    }
+    f32x4 acc[G::NT];
+    float bacc[VW];
+#pragma unroll
+    for (int t = 0; t < G::NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < VW; ++t) bacc[t] = 0.f;
+
+    if (e > s) {
+        accumulate_range<VW, VEC, true>(acc, bacc, p.col, p.val, s, e, p.Y, p.ldy, p.f, p.alpha, lane);
+        reduce_b<VW>(bacc);
+    }
+    if (it.chunk >= 0) {
+        float *P = p.partials + (int64_t)it.slot * (G::PQ * 64);
+#pragma unroll
+        for (int t = 0; t < G::NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[(t * 4 + r) * 64 + lane] = acc[t][r];
+#pragma unroll
+        for (int t = 0; t < VW; ++t) P[(G::TQ + t) * 64 + lane] = bacc[t];
+        return;
+    }
+    const int64_t xr = p.row_ids ? p.row_ids[row] : (int64_t)row;
+    float *xrow = p.X + xr * p.ldx;
+    float d;
+    if (e > s) {
+        d = solve_row<VW>(acc, bacc, p.gtiles, lds, p.f, xrow, p.info, lane);
+    } else {  // no entries: b = 0, so x = 0 exactly
+        d = 0.f;
+        if (lane < p.f) {
+            d = fabsf(xrow[lane]);
+            xrow[lane] = 0.f;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) d += __shfl_xor(d, o);
+    }
+    if (lane == 0) p.rowdiff[row] = d;
+}
+
+template <int VW>
+__global__ __launch_bounds__(64) void sweep_long_rows_kernel(const SweepParams p) {
+    using G = Geo<VW>;
+    __shared__ float lds[G::TRI + G::FPAD];
+    const int lane = threadIdx.x;
+    const als_long_row_t lr = p.long_rows[blockIdx.x];
+    f32x4 acc[G::NT];
+    float bacc[VW];
+    const float *P = p.partials + (int64_t)lr.first_slot * (G::PQ * 64);
+#pragma unroll
+    for (int t = 0; t < G::NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = P[(t * 4 + r) * 64 + lane];
+#pragma unroll
+    for (int t = 0; t < VW; ++t) bacc[t] = P[(G::TQ + t) * 64 + lane];
+    for (int c = 1; c < lr.n_chunks; ++c) {
+        P += G::PQ * 64;
+#pragma unroll
+        for (int t = 0; t < G::NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][r] += P[(t * 4 + r) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < VW; ++t) bacc[t] += P[(G::TQ + t) * 64 + lane];
+    }
+    const int row = lr.row;
+    const int64_t xr = p.row_ids ? p.row_ids[row] : (int64_t)row;
+    const float d = solve_row<VW>(acc, bacc, p.gtiles, lds, p.f, p.X + xr * p.ldx, p.info, lane);
+    if (lane == 0) p.rowdiff[row] = d;
+}
+
+// Gram, level 1: one wave per ALS_GRAM_CHUNK_ROWS rows of Y[row0 .. n_end).
+template <int VW, bool VEC>
+__global__ __launch_bounds__(64) void gram_chunk_kernel(const float *__restrict__ Y, const int64_t row0,
+                                                       const int64_t n_end, const int64_t ld, const int f,
+                                                       float *__restrict__ out) {
+    using G = Geo<VW>;
+    const int lane = threadIdx.x;
+    const int64_t s = row0 + (int64_t)blockIdx.x * ALS_GRAM_CHUNK_ROWS;
+    const int64_t e = min(n_end, s + (int64_t)ALS_GRAM_CHUNK_ROWS);
+    f32x4 acc[G::NT];
+    float bacc[VW];
+#pragma unroll
+    for (int t = 0; t < G::NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < VW; ++t) bacc[t] = 0.f;
+    if (e > s) accumulate_range<VW, VEC, false>(acc, bacc, nullptr, nullptr, s, e, Y, ld, f, 1.0f, lane);
+    float *P = out + (int64_t)blockIdx.x * (G::TQ * 64);
+#pragma unroll
+    for (int t = 0; t < G::NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P[(t * 4 + r) * 64 + lane] = acc[t][r];
+}
+
+// out[g][e] = in[g*group][e] + in[g*group+1][e] + ... (in order), e < elems
+__global__ void sum_groups_kernel(const float *__restrict__ in, const int64_t n_in, const int group,
+                                  const int elems, float *__restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= elems) return;
+    const int64_t g = blockIdx.y;
+    const int64_t first = g * group;
+    const int64_t last = min(n_in, first + group);
+    float acc = in[first * elems + e];
+    for (int64_t i = first + 1; i < last; ++i) acc += in[i * elems + e];
+    out[g * elems + e] = acc;
+}
+
+// Sums the second-level partials in order, then writes the row-major Gram and the tile-order
+// copy with lamb on the diagonal.
+template <int VW>
+__global__ void gram_finalize_kernel(const float *__restrict__ super, const int64_t n_super, const int f,
+                                     const float lamb, float *__restrict__ gram_out,
+                                     float *__restrict__ tiles_out) {
+    using G = Geo<VW>;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= G::TQ * 64) return;
+    float v = super[e];
+    for (int64_t i = 1; i < n_super; ++i) v += super[i * (G::TQ * 64) + e];
+    const int lane = e & 63, q = e >> 6, r = q & 3, t = q >> 2;
+    int ta = 0, tb = 0;
+    for (int a = 0; a < VW; ++a)
+        for (int b = a; b < VW; ++b)
+            if (tile_index(a, b, VW) == t) {
+                ta = a;
+                tb = b;
+            }
+    const int i = (lane >> 4) * 4 + r, j = lane & 15;
+    const int ai = fidx<VW>(i, ta), bi = fidx<VW>(j, tb);
+    tiles_out[e] = (ai == bi && ai < f) ? v + lamb : v;
+    if (ai < f && bi < f && (ta != tb || i >= j)) {
+        gram_out[ai * f + bi] = v;
+        gram_out[bi * f + ai] = v;
+    }
+}
+
+// level 1: block b sums rowdiff[b*8192 .. ) into a double; level 2 (single block) sums those.
+constexpr int DIFF_BLOCK_ROWS = 8192;
+template <typename T>
+__global__ __launch_bounds__(256) void sum_to_double_kernel(const T *__restrict__ in, const int64_t n,
+                                                           const int per_block, double *__restrict__ out) {
+    __shared__ double sh[256];
+    const int64_t first = (int64_t)blockIdx.x * per_block;
+    const int64_t last = min(n, first + per_block);
+    double acc = 0.0;
+    for (int64_t i = first + threadIdx.x; i < last; i += 256) acc += (double)in[i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
+}
+
+// ----------------------------------------------------------------------------- host helpers
+inline int vw_for(int f) { return f <= 16 ? 1 : f <= 32 ? 2 : f <= 64 ? 4 : 8; }
+inline int tq_for(int f) {
+    const int vw = vw_for(f);
+    return vw * (vw + 1) / 2 * 4;
+}
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+inline bool vec_ok(const float *p, int64_t ld, int f) {
+    const int vw = vw_for(f);
+    if (vw == 1) return true;
+    const int w = vw >= 4 ? 4 : 2;
+    return (f % w == 0) && (ld % w == 0) && ((uintptr_t)p % (4 * w) == 0);
+}
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+template <int VW>
+static int32_t gram_partials_impl(const float *Y, int64_t row_begin, int64_t row_end, int32_t f, int64_t ldy,
+                                  float *super_out, void *workspace, hipStream_t st) {
+    using G = Geo<VW>;
+    const int64_t n = row_end - row_begin;
+    const int64_t n_chunks = ceil_div(n, ALS_GRAM_CHUNK_ROWS);
+    const int64_t n_super = ceil_div(n, ALS_GRAM_SUPER_ROWS);
+    float *chunks = (float *)workspace;
+    if (vec_ok(Y, ldy, f))
+        hipLaunchKernelGGL((gram_chunk_kernel<VW, true>), dim3((unsigned)n_chunks), dim3(64), 0, st, Y, row_begin, row_end,
+                           ldy, f, chunks);
+    else
+        hipLaunchKernelGGL((gram_chunk_kernel<VW, false>), dim3((unsigned)n_chunks), dim3(64), 0, st, Y, row_begin,
+                           row_end, ldy, f, chunks);
+    ALS_HIP_CHECK(hipGetLastError());
+    const int elems = G::TQ * 64;
+    hipLaunchKernelGGL(sum_groups_kernel, dim3((elems + 255) / 256, (unsigned)n_super), dim3(256), 0, st, chunks, n_chunks,
+                       ALS_GRAM_SUPER_ROWS / ALS_GRAM_CHUNK_ROWS, elems, super_out);
+    ALS_HIP_CHECK(hipGetLastError());
+    return ALS_OK;
+}
+
+template <int VW>
+static int32_t half_sweep_impl(const SweepParams &p, int64_t n_rows, int64_t n_items, int64_t n_long,
+                               double *absdiff_out, double *diff_partials, bool vec, hipStream_t st) {
+    if (n_items > 0) {
+        if (vec)
+            hipLaunchKernelGGL((sweep_items_kernel<VW, true>), dim3((unsigned)n_items), dim3(64), 0, st, p);
+        else
+            hipLaunchKernelGGL((sweep_items_kernel<VW, false>), dim3((unsigned)n_items), dim3(64), 0, st, p);
+        ALS_HIP_CHECK(hipGetLastError());
+    }
+    if (n_long > 0) {
+        hipLaunchKernelGGL(sweep_long_rows_kernel<VW>, dim3((unsigned)n_long), dim3(64), 0, st, p);
+        ALS_HIP_CHECK(hipGetLastError());
+    }
+    if (absdiff_out) {
+        const int64_t nb = ceil_div(n_rows, DIFF_BLOCK_ROWS);
+        hipLaunchKernelGGL(sum_to_double_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, p.rowdiff, n_rows,
+                           DIFF_BLOCK_ROWS, diff_partials);
+        ALS_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(sum_to_double_kernel<double>, dim3(1), dim3(256), 0, st, diff_partials, nb, (int)nb,
+                           absdiff_out);
+        ALS_HIP_CHECK(hipGetLastError());
+    }
+    return ALS_OK;
+}
+
+}  // namespace
+
+// ============================================================================= C ABI
+extern "C" {
+
+const char *als_last_error_string(void) { return g_err; }
+int32_t als_abi_version(void) { return 1; }
+
+// ----------------------------------------------------------------------------- plan
+int32_t als_plan_count(const int64_t *rowptr, int64_t n_rows, int32_t chunk_nnz, int64_t *n_items, int64_t *n_long,
+                       int64_t *n_slots) {
+    if (!rowptr || n_rows < 0 || !n_items || !n_long || !n_slots)
+        return fail(ALS_ERR_INVALID_ARG, "als_plan_count: null pointer or negative n_rows");
+    if (chunk_nnz < 64 || chunk_nnz % 64) return fail(ALS_ERR_INVALID_ARG, "chunk_nnz must be a positive multiple of 64");
+    if (n_rows > INT32_MAX) return fail(ALS_ERR_UNSUPPORTED, "more than 2^31-1 rows in one plan");
+    int64_t items = 0, lng = 0, slots = 0;
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const int64_t nnz = rowptr[r + 1] - rowptr[r];
+        if (nnz < 0) return fail(ALS_ERR_INVALID_ARG, "rowptr is not non-decreasing at row %lld", (long long)r);
+        if (nnz > chunk_nnz) {
+            const int64_t c = ceil_div(nnz, chunk_nnz);
+            items += c;
+            slots += c;
+            lng += 1;
+        } else {
+            items += 1;
+        }
+    }
+    if (slots > INT32_MAX) return fail(ALS_ERR_UNSUPPORTED, "too many partial slots");
+    *n_items = items;
+    *n_long = lng;
+    *n_slots = slots;
+    return ALS_OK;
+}
+
+int32_t als_plan_fill(const int64_t *rowptr, int64_t n_rows, int32_t chunk_nnz, als_item_t *items,
+                      als_long_row_t *long_rows) {
+    int64_t n_items, n_long, n_slots;
+    const int32_t rc = als_plan_count(rowptr, n_rows, chunk_nnz, &n_items, &n_long, &n_slots);
+    if (rc) return rc;
+    if (!items || (n_long && !long_rows)) return fail(ALS_ERR_INVALID_ARG, "als_plan_fill: null output");
+    // chunk items first (the largest work units), rows in order
+    int64_t pos = 0, lpos = 0;
+    int32_t slot = 0;
+    std::vector<int64_t> bucket(chunk_nnz + 2, 0);  // counting sort of the short rows by nnz, descending
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const int64_t nnz = rowptr[r + 1] - rowptr[r];
+        if (nnz > chunk_nnz) {
+            const int32_t c = (int32_t)ceil_div(nnz, chunk_nnz);
+            long_rows[lpos++] = als_long_row_t{(int32_t)r, slot, c, 0};
+            for (int32_t k = 0; k < c; ++k) items[pos++] = als_item_t{(int32_t)r, k, slot++, 0};
+        } else {
+            bucket[chunk_nnz - nnz + 1] += 1;  // key = chunk_nnz - nnz: longest rows first
+        }
+    }
+    for (int64_t k = 1; k < (int64_t)bucket.size(); ++k) bucket[k] += bucket[k - 1];
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const int64_t nnz = rowptr[r + 1] - rowptr[r];
+        if (nnz <= chunk_nnz) items[pos + bucket[chunk_nnz - nnz]++] = als_item_t{(int32_t)r, -1, -1, 0};
+    }
+    return ALS_OK;
+}
+
+// ----------------------------------------------------------------------------- gram
+size_t als_gram_tiles_bytes(int32_t f) {
+    if (f < 1 || f > ALS_MAX_FACTORS) return 0;
+    return (size_t)tq_for(f) * 64 * sizeof(float);
+}
+
+size_t als_gram_workspace_bytes(int64_t n, int32_t f) {
+    if (f < 1 || f > ALS_MAX_FACTORS || n < 0) return 0;
+    const size_t tile = als_gram_tiles_bytes(f);
+    const int64_t n_chunks = std::max<int64_t>(1, ceil_div(n, ALS_GRAM_CHUNK_ROWS));
+    const int64_t n_super = std::max<int64_t>(1, ceil_div(n, ALS_GRAM_SUPER_ROWS));
+    return (size_t)(n_chunks + n_super) * tile + 256;
+}
+
+int32_t als_gram_partials_f32(const float *Y, int64_t row_begin, int64_t row_end, int32_t f, int64_t ldy,
+                              float *super_out, void *workspace, size_t ws_bytes, void *stream) {
+    if (!Y || !super_out || !workspace) return fail(ALS_ERR_INVALID_ARG, "als_gram_partials_f32: null pointer");
+    if (f < 1 || f > ALS_MAX_FACTORS) return fail(ALS_ERR_UNSUPPORTED, "f=%d outside [1, %d]", f, ALS_MAX_FACTORS);
+    if (row_begin < 0 || row_end <= row_begin || row_begin % ALS_GRAM_SUPER_ROWS)
+        return fail(ALS_ERR_INVALID_ARG, "row range [%lld, %lld) empty or row_begin not a multiple of %d",
+                    (long long)row_begin, (long long)row_end, ALS_GRAM_SUPER_ROWS);
+    if (row_end > INT32_MAX) return fail(ALS_ERR_UNSUPPORTED, "more than 2^31-1 factor rows");
+    if (ldy < f) return fail(ALS_ERR_INVALID_ARG, "ldy < f");
+    if (ws_bytes < als_gram_workspace_bytes(row_end - row_begin, f))
+        return fail(ALS_ERR_WORKSPACE, "gram workspace too small: %zu < %zu", ws_bytes,
+                    als_gram_workspace_bytes(row_end - row_begin, f));
+    hipStream_t st = (hipStream_t)stream;
+    switch (vw_for(f)) {
+        case 1: return gram_partials_impl<1>(Y, row_begin, row_end, f, ldy, super_out, workspace, st);
+        case 2: return gram_partials_impl<2>(Y, row_begin, row_end, f, ldy, super_out, workspace, st);
+        case 4: return gram_partials_impl<4>(Y, row_begin, row_end, f, ldy, super_out, workspace, st);
+        default: return fail(ALS_ERR_UNSUPPORTED, "f=%d: exact path supports f <= 64 in this build", f);
+    }
+}
+
+int32_t als_gram_finalize_f32(const float *super_in, int64_t n_super, int32_t f, float lamb, float *gram_out,
+                              float *tiles_out, void *stream) {
+    if (!super_in || !gram_out || !tiles_out || n_super < 1)
+        return fail(ALS_ERR_INVALID_ARG, "als_gram_finalize_f32: null pointer or n_super < 1");
+    if (f < 1 || f > ALS_MAX_FACTORS) return fail(ALS_ERR_UNSUPPORTED, "f=%d outside [1, %d]", f, ALS_MAX_FACTORS);
+    hipStream_t st = (hipStream_t)stream;
+    const int elems = tq_for(f) * 64;
+    const dim3 grid((elems + 255) / 256), block(256);
+    switch (vw_for(f)) {
+        case 1: hipLaunchKernelGGL(gram_finalize_kernel<1>, grid, block, 0, st, super_in, n_super, f, lamb, gram_out, tiles_out); break;
+        case 2: hipLaunchKernelGGL(gram_finalize_kernel<2>, grid, block, 0, st, super_in, n_super, f, lamb, gram_out, tiles_out); break;
+        case 4: hipLaunchKernelGGL(gram_finalize_kernel<4>, grid, block, 0, st, super_in, n_super, f, lamb, gram_out, tiles_out); break;
+        default: return fail(ALS_ERR_UNSUPPORTED, "f=%d: exact path supports f <= 64 in this build", f);
+    }
+    ALS_HIP_CHECK(hipGetLastError());
+    return ALS_OK;
+}
+
+int32_t als_gram_f32(const float *Y, int64_t n, int32_t f, int64_t ldy, float lamb, float *gram_out, float *tiles_out,
+                     void *workspace, size_t ws_bytes, void *stream) {
+    if (n < 1) return fail(ALS_ERR_INVALID_ARG, "als_gram_f32: n < 1");
+    if (!workspace || ws_bytes < als_gram_workspace_bytes(n, f) || als_gram_workspace_bytes(n, f) == 0)
+        return fail(ALS_ERR_WORKSPACE, "gram workspace too small or f unsupported");
+    const size_t tile = als_gram_tiles_bytes(f);
+    const int64_t n_chunks = ceil_div(n, ALS_GRAM_CHUNK_ROWS);
+    const int64_t n_super = ceil_div(n, ALS_GRAM_SUPER_ROWS);
+    float *super = (float *)((char *)workspace + (size_t)n_chunks * tile);
+    int32_t rc = als_gram_partials_f32(Y, 0, n, f, ldy, super, workspace, ws_bytes, stream);
+    if (rc) return rc;
+    return als_gram_finalize_f32(super, n_super, f, lamb, gram_out, tiles_out, stream);
+}
+
+// ----------------------------------------------------------------------------- half sweep
+size_t als_half_sweep_workspace_bytes(int64_t n_rows, int64_t n_slots, int32_t f) {
+    if (f < 1 || f > ALS_MAX_FACTORS || n_rows < 0 || n_slots < 0) return 0;
+    const int vw = vw_for(f);
+    const size_t pq = (size_t)(vw * (vw + 1) / 2 * 4 + vw) * 64 * sizeof(float);
+    size_t b = align_up((size_t)n_slots * pq, 256);
+    b += align_up((size_t)n_rows * sizeof(float), 256);
+    b += align_up((size_t)(ceil_div(n_rows, DIFF_BLOCK_ROWS) + 1) * sizeof(double), 256);
+    return b + 256;
+}
+
+int32_t als_half_sweep_csr_f32(const int64_t *rowptr, const int32_t *col, const float *val, int64_t n_rows,
+                               const int64_t *row_ids, const als_item_t *items, int64_t n_items,
+                               const als_long_row_t *long_rows, int64_t n_long, int64_t n_slots, int32_t chunk_nnz,
+                               const float *Yopp, int64_t n_opp, int64_t ldy, const float *gram_tiles, int32_t f,
+                               float alpha, float *Xown, int64_t ldx, double *absdiff_out, int32_t *info_out,
+                               void *workspace, size_t ws_bytes, void *stream) {
+    if (!rowptr || !items || !Yopp || !gram_tiles || !Xown || !workspace)
+        return fail(ALS_ERR_INVALID_ARG, "als_half_sweep_csr_f32: null pointer");
+    if (n_rows < 1 || n_rows > INT32_MAX || n_items < n_rows || n_long < 0 || n_slots < 0 || n_opp < 1)
+        return fail(ALS_ERR_INVALID_ARG, "als_half_sweep_csr_f32: bad sizes (n_rows=%lld n_items=%lld n_opp=%lld)",
+                    (long long)n_rows, (long long)n_items, (long long)n_opp);
+    if ((n_long > 0 && !long_rows) || (n_long > 0) != (n_slots > 0) || n_items != n_rows - n_long + n_slots)
+        return fail(ALS_ERR_INVALID_ARG, "plan sizes are inconsistent (n_items=%lld n_long=%lld n_slots=%lld)",
+                    (long long)n_items, (long long)n_long, (long long)n_slots);
+    if (chunk_nnz < 64 || chunk_nnz % 64) return fail(ALS_ERR_INVALID_ARG, "chunk_nnz must be a positive multiple of 64");
+    if (f < 1 || f > ALS_MAX_FACTORS) return fail(ALS_ERR_UNSUPPORTED, "f=%d outside [1, %d]", f, ALS_MAX_FACTORS);
+    if (ldy < f || ldx < f) return fail(ALS_ERR_INVALID_ARG, "leading dimension smaller than f");
+    if (n_items > 0x7fffffffLL) return fail(ALS_ERR_UNSUPPORTED, "too many work items for one launch");
+    if (ws_bytes < als_half_sweep_workspace_bytes(n_rows, n_slots, f))
+        return fail(ALS_ERR_WORKSPACE, "half-sweep workspace too small: %zu < %zu", ws_bytes,
+                    als_half_sweep_workspace_bytes(n_rows, n_slots, f));
+    if ((!col || !val) && rowptr) {
+        // a CSR without stored entries is legal only if every row is empty; the kernels never
+        // dereference col/val then, but a null with entries would fault: refuse it here.
+        return fail(ALS_ERR_INVALID_ARG, "col/val are null");
+    }
+    const int vw = vw_for(f);
+    const size_t pq = (size_t)(vw * (vw + 1) / 2 * 4 + vw) * 64 * sizeof(float);
+    char *ws = (char *)workspace;
+    SweepParams p;
+    p.rowptr = rowptr; p.col = col; p.val = val; p.row_ids = row_ids; p.items = items; p.long_rows = long_rows;
+    p.Y = Yopp; p.gtiles = gram_tiles; p.X = Xown;
+    p.partials = (float *)ws; ws += align_up((size_t)n_slots * pq, 256);
+    p.rowdiff = (float *)ws; ws += align_up((size_t)n_rows * sizeof(float), 256);
+    double *diff_partials = (double *)ws;
+    p.info = info_out; p.ldy = ldy; p.ldx = ldx; p.f = f; p.chunk_nnz = chunk_nnz; p.alpha = alpha;
+    const bool vec = vec_ok(Yopp, ldy, f);
+    hipStream_t st = (hipStream_t)stream;
+    switch (vw) {
+        case 1: return half_sweep_impl<1>(p, n_rows, n_items, n_long, absdiff_out, diff_partials, vec, st);
+        case 2: return half_sweep_impl<2>(p, n_rows, n_items, n_long, absdiff_out, diff_partials, vec, st);
+        case 4: return half_sweep_impl<4>(p, n_rows, n_items, n_long, absdiff_out, diff_partials, vec, st);
+        default: return fail(ALS_ERR_UNSUPPORTED, "f=%d: exact path supports f <= 64 in this build", f);
+    }
+}
+
+}  // extern "C"

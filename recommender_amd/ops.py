@@ -1,0 +1,220 @@
+"""Device-side operators of the ALS hot path: thin torch wrappers over the C ABI.
+
+  DeviceCSR      the CSR the kernels walk (replaces the padded batches of
+                 reclibwh/data/iterators.py:160-193 + reclibwh/utils/utils.py:142-173)
+  gram           als_update_cache        (reclibwh/core/ALS.py:235-246)
+  half_sweep     run_als_epoch / run_als_step / als_run_regression
+                                          (reclibwh/core/ALS.py:160-233)
+
+torch is used for device memory and streams only; every computation is a HIP kernel
+in libals_hip.so.  Arguments are validated here (dtype, contiguity, device, index
+range) so that the kernels can assume well-formed input.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need(t, dtype, name, dim=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise ValueError("%s must be a CUDA/HIP tensor" % name)
+    if t.dtype != dtype:
+        raise ValueError("%s must have dtype %s, got %s" % (name, dtype, t.dtype))
+    if dim is not None and t.dim() != dim:
+        raise ValueError("%s must be %d-dimensional" % (name, dim))
+
+
+def _factor_ld(t, name):
+    """Row-major [n, f] with unit inner stride; returns the leading dimension in elements."""
+    _need(t, torch.float32, name, 2)
+    if t.stride(1) != 1 or t.stride(0) < t.shape[1]:
+        raise ValueError("%s must be row-major with unit inner stride" % name)
+    return t.stride(0)
+
+
+# ----------------------------------------------------------------------------- plan (host only)
+def build_plan(indptr, chunk_nnz=_lib.DEFAULT_CHUNK_NNZ):
+    """Row schedule for a CSR row-pointer array (host numpy int64).  Returns
+    (items [n_items, 4] int32, long_rows [n_long, 4] int32, n_slots)."""
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    n_rows = indptr.shape[0] - 1
+    if n_rows < 0:
+        raise ValueError("indptr must have at least one entry")
+    ni, nl, ns = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    check(lib.als_plan_count(indptr.ctypes.data, n_rows, chunk_nnz, ctypes.byref(ni), ctypes.byref(nl),
+                             ctypes.byref(ns)), "als_plan_count")
+    items = np.empty((ni.value, 4), dtype=np.int32)
+    long_rows = np.empty((max(nl.value, 1), 4), dtype=np.int32)
+    check(lib.als_plan_fill(indptr.ctypes.data, n_rows, chunk_nnz, items.ctypes.data, long_rows.ctypes.data),
+          "als_plan_fill")
+    return items, long_rows[: nl.value], int(ns.value)
+
+
+class DeviceCSR:
+    """CSR matrix resident in HBM (int64 row pointers, int32 columns, float32 values) plus its
+    row schedule.  `row_ids`, if given, maps CSR row u to the factor row it updates."""
+
+    def __init__(self, indptr, indices, data, shape, device, chunk_nnz=_lib.DEFAULT_CHUNK_NNZ, row_ids=None):
+        indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(indices, dtype=np.int32)
+        data = np.ascontiguousarray(data, dtype=np.float32)
+        n_rows, n_cols = int(shape[0]), int(shape[1])
+        if indptr.shape[0] != n_rows + 1 or indptr[0] != 0 or indptr[-1] != indices.shape[0] \
+                or indices.shape[0] != data.shape[0]:
+            raise ValueError("inconsistent CSR arrays")
+        if n_rows < 1:
+            raise ValueError("CSR needs at least one row")
+        if np.any(np.diff(indptr) < 0):
+            raise ValueError("indptr must be non-decreasing")
+        if indices.size and (indices.min() < 0 or indices.max() >= n_cols):
+            raise ValueError("column index out of range [0, %d)" % n_cols)
+        self.shape = (n_rows, n_cols)
+        self.nnz = int(indices.shape[0])
+        self.chunk_nnz = int(chunk_nnz)
+        self.device = torch.device(device)
+        items, long_rows, self.n_slots = build_plan(indptr, chunk_nnz)
+        self.n_items, self.n_long = items.shape[0], long_rows.shape[0]
+        dev = self.device
+        self.rowptr = torch.from_numpy(indptr).to(dev)
+        self.device = dev = self.rowptr.device        # normalised ("cuda" -> "cuda:0")
+        # one spare element keeps the pointers non-null for a matrix without entries
+        self.col = torch.from_numpy(np.concatenate([indices, np.zeros(1, np.int32)])).to(dev)
+        self.val = torch.from_numpy(np.concatenate([data, np.zeros(1, np.float32)])).to(dev)
+        self.items = torch.from_numpy(items).to(dev)
+        self.long_rows = torch.from_numpy(long_rows).to(dev) if self.n_long else None
+        self.row_ids = None
+        if row_ids is not None:
+            row_ids = np.ascontiguousarray(row_ids, dtype=np.int64)
+            if row_ids.shape[0] != n_rows or (row_ids.size and row_ids.min() < 0):
+                raise ValueError("row_ids must hold one non-negative id per CSR row")
+            self.row_ids_max = int(row_ids.max())
+            self.row_ids = torch.from_numpy(row_ids).to(dev)
+        self._ws = {}
+
+    @classmethod
+    def from_scipy(cls, U, device, chunk_nnz=_lib.DEFAULT_CHUNK_NNZ, row_ids=None):
+        import scipy.sparse as sps
+        U = sps.csr_matrix(U)
+        U.sort_indices()
+        return cls(U.indptr, U.indices, U.data, U.shape, device, chunk_nnz, row_ids)
+
+    def workspace(self, f):
+        ws = self._ws.get(f)
+        if ws is None:
+            nbytes = lib.als_half_sweep_workspace_bytes(self.shape[0], self.n_slots, f)
+            if nbytes == 0:
+                raise ValueError("unsupported factor count f=%d" % f)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws[f] = ws
+        return ws
+
+
+# ----------------------------------------------------------------------------- gram
+class GramCache:
+    """Y^T Y (`gram`, [f, f]) and its kernel-order copy with lamb*I added (`tiles`):
+    the Y2 / LambdaI pair of reclibwh/core/ALS.py:235-246."""
+
+    def __init__(self, f, lamb, device):
+        nbytes = lib.als_gram_tiles_bytes(f)
+        if nbytes == 0:
+            raise ValueError("unsupported factor count f=%d (1..%d)" % (f, _lib.MAX_FACTORS))
+        self.f, self.lamb = int(f), float(lamb)
+        self.gram = torch.zeros((f, f), dtype=torch.float32, device=device)
+        self.tiles = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+        self._ws = None
+
+
+def gram(Y, lamb, out=None, n=None):
+    """als_update_cache: Gram of the first n rows of Y (default all) and lamb*I."""
+    ldy = _factor_ld(Y, "Y")
+    n = Y.shape[0] if n is None else int(n)
+    f = Y.shape[1]
+    if n < 1 or n > Y.shape[0]:
+        raise ValueError("n out of range")
+    if out is None:
+        out = GramCache(f, lamb, Y.device)
+    out.lamb = float(lamb)
+    need = lib.als_gram_workspace_bytes(n, f)
+    if out._ws is None or out._ws.numel() < need:
+        out._ws = torch.empty(need, dtype=torch.uint8, device=Y.device)
+    check(lib.als_gram_f32(_ptr(Y), n, f, ldy, float(lamb), _ptr(out.gram), _ptr(out.tiles), _ptr(out._ws),
+                           out._ws.numel(), _stream()), "als_gram_f32")
+    return out
+
+
+def gram_partials(Y, row_begin, row_end, super_out=None, ws=None):
+    """Second-level Gram partials of rows [row_begin, row_end) (row_begin a multiple of
+    GRAM_SUPER_ROWS); returns a [n_super, tile_elems] float32 tensor."""
+    ldy = _factor_ld(Y, "Y")
+    f = Y.shape[1]
+    if not (0 <= row_begin < row_end <= Y.shape[0]):
+        raise ValueError("bad row range")
+    n_super = -(-(row_end - row_begin) // _lib.GRAM_SUPER_ROWS)
+    elems = lib.als_gram_tiles_bytes(f) // 4
+    if elems == 0:
+        raise ValueError("unsupported factor count f=%d" % f)
+    if super_out is None:
+        super_out = torch.empty((n_super, elems), dtype=torch.float32, device=Y.device)
+    need = lib.als_gram_workspace_bytes(row_end - row_begin, f)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=Y.device)
+    check(lib.als_gram_partials_f32(_ptr(Y), row_begin, row_end, f, ldy, _ptr(super_out), _ptr(ws), ws.numel(),
+                                    _stream()), "als_gram_partials_f32")
+    return super_out
+
+
+def gram_finalize(super_partials, f, lamb, out=None):
+    _need(super_partials, torch.float32, "super_partials", 2)
+    if not super_partials.is_contiguous():
+        raise ValueError("super_partials must be contiguous")
+    if out is None:
+        out = GramCache(f, lamb, super_partials.device)
+    out.lamb = float(lamb)
+    check(lib.als_gram_finalize_f32(_ptr(super_partials), super_partials.shape[0], f, float(lamb), _ptr(out.gram),
+                                    _ptr(out.tiles), _stream()), "als_gram_finalize_f32")
+    return out
+
+
+# ----------------------------------------------------------------------------- half sweep
+def half_sweep(csr, Yopp, gram_cache, Xown, alpha, absdiff=None, info=None):
+    """One half-sweep: every row of `csr` re-solves its row of Xown (in place) against the
+    fixed factor Yopp.  Returns the device scalar sum|X_old - X_new| (float64, 1 element);
+    divide by n*k for run_als_epoch's return value (reclibwh/core/ALS.py:233)."""
+    if not isinstance(csr, DeviceCSR):
+        raise ValueError("csr must be a DeviceCSR")
+    ldy = _factor_ld(Yopp, "Yopp")
+    ldx = _factor_ld(Xown, "Xown")
+    f = Yopp.shape[1]
+    if Xown.shape[1] != f or gram_cache.f != f:
+        raise ValueError("factor counts differ: Yopp %d, Xown %d, gram %d" % (f, Xown.shape[1], gram_cache.f))
+    if Yopp.shape[0] < csr.shape[1]:
+        raise ValueError("Yopp has %d rows but the CSR has %d columns" % (Yopp.shape[0], csr.shape[1]))
+    need_rows = (csr.row_ids_max + 1) if csr.row_ids is not None else csr.shape[0]
+    if Xown.shape[0] < need_rows:
+        raise ValueError("Xown has %d rows, the CSR updates row %d" % (Xown.shape[0], need_rows - 1))
+    if Yopp.device != csr.device or Xown.device != csr.device:
+        raise ValueError("tensors live on different devices")
+    if Xown.data_ptr() == Yopp.data_ptr():
+        raise ValueError("Xown and Yopp must not alias")
+    if absdiff is None:
+        absdiff = torch.zeros(1, dtype=torch.float64, device=csr.device)
+    ws = csr.workspace(f)
+    with torch.cuda.device(csr.device):
+        check(lib.als_half_sweep_csr_f32(
+            _ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.val), csr.shape[0], _ptr(csr.row_ids), _ptr(csr.items),
+            csr.n_items, _ptr(csr.long_rows), csr.n_long, csr.n_slots, csr.chunk_nnz, _ptr(Yopp), csr.shape[1], ldy,
+            _ptr(gram_cache.tiles), f, float(alpha), _ptr(Xown), ldx, _ptr(absdiff), _ptr(info), _ptr(ws),
+            ws.numel(), _stream()), "als_half_sweep_csr_f32")
+    return absdiff
