@@ -135,6 +135,12 @@ int32_t als_half_sweep_csr_f32(const int64_t *rowptr, const int32_t *col, const 
                                double *absdiff_out, int32_t *info_out, void *workspace, size_t ws_bytes,
                                void *stream);
 
+/* Profiling tap (no reference counterpart; for benchmarks): the next
+ * als_half_sweep_csr_f32 call made by the calling thread records the two hipEvent_t
+ * handles on its stream immediately before and after its per-row gather/accumulate
+ * kernel, then forgets them.  Pass NULLs to clear. */
+int32_t als_profile_tap_next_sweep(void *ev_begin, void *ev_end);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,8 +7,12 @@ or `make -C recommender_amd/csrc`.
 import ctypes
 import os
 
+import torch  # noqa: F401  must precede the CDLL below: the library has to bind to the HIP runtime
+              # (libamdhip64.so.7) that torch loads, or the process ends up with two runtimes
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libals_hip.so")
+# ALS_HIP_LIB selects another build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("ALS_HIP_LIB") or os.path.join(_HERE, "libals_hip.so")
 
 ALS_OK = 0
 ERROR_NAMES = {1: "invalid argument", 2: "unsupported", 3: "workspace too small", 4: "HIP error"}
@@ -30,6 +34,7 @@ SIGNATURES = {
     "als_gram_f32": (c_i32, [c_vp, c_i64, c_i32, c_i64, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "als_gram_partials_f32": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i64, c_vp, c_vp, c_sz, c_vp]),
     "als_gram_finalize_f32": (c_i32, [c_vp, c_i64, c_i32, c_f32, c_vp, c_vp, c_vp]),
+    "als_profile_tap_next_sweep": (c_i32, [c_vp, c_vp]),
     "als_half_sweep_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32]),
     "als_half_sweep_csr_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32,
                                        c_vp, c_i64, c_i64, c_vp, c_i32, c_f32, c_vp, c_i64, c_vp, c_vp, c_vp, c_sz,

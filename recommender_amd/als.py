@@ -1,0 +1,171 @@
+"""Implicit-ALS training engine (Hu-Koren-Volinsky) on MI355X.
+
+Host-side mirror of the reference's algorithm layer, reclibwh/core/ALS.py:
+
+  init_factors        ALSRef.__init__ (ALS.py:56-65) / als_initizalize (ALS.py:248-260)
+  als_update_cache    ALS.py:235-246
+  run_als_epoch       ALS.py:201-233   (one half-sweep; returns mean |delta| per element)
+  ALSEngine.fit       ALSTrainer.fit (ALS.py:320-357) / ALSRef.train (ALS.py:122-141)
+
+One process drives one GPU.  With torch.distributed initialised (backend "nccl" = RCCL on
+ROCm, "gloo" in CPU tests) every rank keeps full replicas of X and Y, sweeps its own
+contiguous shard of user rows (then item rows) and the shards are all-gathered after each
+half-sweep; the Gram is summed from fixed 65 536-row partials in row order on every rank, so
+factors are bit-identical to a single-GPU run for any world size.
+"""
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+
+# ----------------------------------------------------------------------------- init
+def init_factors(n_users, n_items, f, convention="ref", seed=42):
+    """Initial factors ~ N(0, 1/sqrt(f)) from numpy's legacy MT19937 global stream, float64.
+
+    "ref": re-seed before X and before Y, as ALSRef.__init__ does (ALS.py:59-65).
+    "tf":  seed once, draw X then Y, as als_initizalize does (ALS.py:255-257); pass the
+           layer row counts (N+1, M+1 in the training script, ALS.py:456) to reproduce it.
+    """
+    if convention not in ("ref", "tf"):
+        raise ValueError("convention must be 'ref' or 'tf'")
+    np.random.seed(seed)
+    X = np.random.normal(0, 1 / np.sqrt(f), size=(n_users, f))
+    if convention == "ref":
+        np.random.seed(seed)
+    Y = np.random.normal(0, 1 / np.sqrt(f), size=(n_items, f))
+    return X, Y
+
+
+def balanced_ranges(rowptr, parts):
+    """Split rows into `parts` contiguous ranges with about equal stored entries (prefix sum
+    on the row pointers).  rowptr: host int64 array.  Returns parts+1 boundaries."""
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    n = rowptr.shape[0] - 1
+    total = int(rowptr[-1])
+    if total == 0:
+        return np.linspace(0, n, parts + 1).astype(np.int64)
+    targets = (np.arange(1, parts, dtype=np.float64) * total / parts)
+    cuts = np.searchsorted(rowptr, targets, side="left").astype(np.int64)
+    b = np.concatenate([[0], cuts, [n]]).astype(np.int64)
+    return np.maximum.accumulate(np.clip(b, 0, n))
+
+
+# ----------------------------------------------------------------------------- operators
+def als_update_cache(Y, lamb, cache=None, group=None):
+    """Y2 <- Y^T Y over all rows of Y (pad/phantom rows included), LambdaI <- lamb I
+    (ALS.py:235-246).  With a process group, each rank reduces its share of the fixed
+    65 536-row partials and the partials are all-gathered and summed in row order."""
+    world = torch.distributed.get_world_size(group) if group is not None else 1
+    n, f = Y.shape
+    n_super = -(-n // _lib.GRAM_SUPER_ROWS)
+    if world == 1 or n_super < 2 * world:
+        return ops.gram(Y, lamb, out=cache)
+    rank = torch.distributed.get_rank(group)
+    cuts = [(n_super * r) // world for r in range(world + 1)]
+    s0, s1 = cuts[rank], cuts[rank + 1]
+    mine = ops.gram_partials(Y, s0 * _lib.GRAM_SUPER_ROWS, min(n, s1 * _lib.GRAM_SUPER_ROWS))
+    cnt_max = max(cuts[r + 1] - cuts[r] for r in range(world))
+    elems = mine.shape[1]
+    send = torch.zeros((cnt_max, elems), dtype=torch.float32, device=Y.device)
+    send[: mine.shape[0]] = mine
+    recv = torch.empty((world * cnt_max, elems), dtype=torch.float32, device=Y.device)
+    torch.distributed.all_gather_into_tensor(recv, send, group=group)
+    parts = [recv[r * cnt_max: r * cnt_max + (cuts[r + 1] - cuts[r])] for r in range(world)]
+    return ops.gram_finalize(torch.cat(parts, 0).contiguous(), f, lamb, out=cache)
+
+
+def run_als_epoch(csr, X, Y, cache, alpha, absdiff=None, info=None):
+    """One half-sweep over the rows of `csr`: re-solves those rows of X in place against the
+    fixed Y and its cache (ALS.py:201-233).  Returns the device scalar sum|X_old - X_new|
+    (float64); the reference's return value is that divided by n_rows * f."""
+    return ops.half_sweep(csr, Y, cache, X, alpha, absdiff=absdiff, info=info)
+
+
+def _all_gather_rows(T, bounds, rank, group):
+    """In-place all-gather of the row shards [bounds[r], bounds[r+1]) of the replicated T."""
+    world = len(bounds) - 1
+    sizes = [int(bounds[r + 1] - bounds[r]) for r in range(world)]
+    if len(set(sizes)) == 1 and T.is_contiguous() and sizes[0] * world == T.shape[0]:
+        torch.distributed.all_gather_into_tensor(T, T[bounds[rank]:bounds[rank + 1]], group=group)
+        return
+    for r in range(world):
+        if sizes[r]:
+            torch.distributed.broadcast(T[bounds[r]:bounds[r + 1]], src=torch.distributed.get_global_rank(group, r)
+                                        if group is not None else r, group=group)
+
+
+# ----------------------------------------------------------------------------- engine
+class ALSEngine:
+    """Alternating least squares over a user x item CSR and its transpose.
+
+    csr_users / csr_items are this rank's row shards (ops.DeviceCSR): rows
+    [user_bounds[rank], user_bounds[rank+1]) of U and [item_bounds[rank], ...) of U^T, with
+    GLOBAL column ids.  X [n_users(+phantom), f] and Y [n_items(+phantom), f] are full
+    replicas.  Single GPU: bounds = [0, n].
+    """
+
+    def __init__(self, csr_users, csr_items, X, Y, lamb, alpha, user_bounds=None, item_bounds=None, group=None):
+        self.group = group
+        self.world = torch.distributed.get_world_size(group) if group is not None else 1
+        self.rank = torch.distributed.get_rank(group) if group is not None else 0
+        self.csr_users, self.csr_items = csr_users, csr_items
+        self.X, self.Y = X, Y
+        self.f = X.shape[1]
+        self.lamb, self.alpha = float(lamb), float(alpha)
+        self.user_bounds = [0, csr_users.shape[0]] if user_bounds is None else [int(b) for b in user_bounds]
+        self.item_bounds = [0, csr_items.shape[0]] if item_bounds is None else [int(b) for b in item_bounds]
+        if len(self.user_bounds) != self.world + 1 or len(self.item_bounds) != self.world + 1:
+            raise ValueError("need world+1 shard boundaries")
+        u0, u1 = self.user_bounds[self.rank], self.user_bounds[self.rank + 1]
+        i0, i1 = self.item_bounds[self.rank], self.item_bounds[self.rank + 1]
+        if csr_users.shape[0] != u1 - u0 or csr_items.shape[0] != i1 - i0:
+            raise ValueError("CSR shard row counts do not match the shard boundaries")
+        self.n_users, self.n_items = self.user_bounds[-1], self.item_bounds[-1]
+        if X.shape[0] < self.n_users or Y.shape[0] < self.n_items:
+            raise ValueError("factor matrices are smaller than the rating matrix")
+        self.cache_Y = ops.GramCache(self.f, lamb, X.device)
+        self.cache_X = ops.GramCache(self.f, lamb, X.device)
+        self._dX = torch.zeros(1, dtype=torch.float64, device=X.device)
+        self._dY = torch.zeros(1, dtype=torch.float64, device=X.device)
+        self.info = torch.zeros(1, dtype=torch.int32, device=X.device)
+        self.trace = []
+        self.pre_sweep_hook = None     # callable("users" | "items"), run just before each half-sweep launch
+
+    # one ALS iteration = X half-sweep + Y half-sweep, Gram refreshes included
+    def step(self):
+        u0, u1 = self.user_bounds[self.rank], self.user_bounds[self.rank + 1]
+        i0, i1 = self.item_bounds[self.rank], self.item_bounds[self.rank + 1]
+        als_update_cache(self.Y, self.lamb, self.cache_Y, self.group)
+        if u1 > u0:
+            if self.pre_sweep_hook: self.pre_sweep_hook("users")
+            run_als_epoch(self.csr_users, self.X[u0:u1], self.Y, self.cache_Y, self.alpha, self._dX, self.info)
+        if self.world > 1:
+            _all_gather_rows(self.X[: self.n_users], self.user_bounds, self.rank, self.group)
+        als_update_cache(self.X, self.lamb, self.cache_X, self.group)
+        if i1 > i0:
+            if self.pre_sweep_hook: self.pre_sweep_hook("items")
+            run_als_epoch(self.csr_items, self.Y[i0:i1], self.X, self.cache_X, self.alpha, self._dY, self.info)
+        if self.world > 1:
+            _all_gather_rows(self.Y[: self.n_items], self.item_bounds, self.rank, self.group)
+
+    def last_delta(self):
+        """mean|dX| + mean|dY| of the last step, as ALSRef.train's trace (ALS.py:136-139).
+        Synchronises with the device."""
+        d = torch.stack([self._dX[0] / (self.n_users * self.f), self._dY[0] / (self.n_items * self.f)])
+        if self.world > 1:
+            torch.distributed.all_reduce(d, group=self.group)
+        return float(d.sum().item())
+
+    def fit(self, steps, callback=None):
+        """`steps` iterations; records the reference's convergence trace; `callback(step)` runs
+        after each iteration (ALS.py:352)."""
+        for s in range(steps):
+            self.step()
+            self.trace.append(self.last_delta())
+            if callback is not None:
+                callback(s)
+        if int(self.info.item()) != 0:
+            raise FloatingPointError("%d row systems were not positive definite in float32 (lamb too small?)"
+                                     % int(self.info.item()))
+        return self.trace

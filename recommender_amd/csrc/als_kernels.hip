@@ -34,6 +34,7 @@ namespace {
 
 // ----------------------------------------------------------------------------- errors
 thread_local char g_err[512] = "";
+thread_local hipEvent_t g_tap_begin = nullptr, g_tap_end = nullptr;
 
 int fail(int code, const char *fmt, ...) {
     va_list ap;
@@ -72,6 +73,9 @@ __host__ __device__ __forceinline__ constexpr int fidx(int j, int t) {
 }
 
 constexpr int GS = 4;  // k-steps per pipeline stage (16 gathered rows)
+#ifndef ALS_SWEEP_WAVES
+#define ALS_SWEEP_WAVES 3  // waves per SIMD the per-row kernel's register budget is sized for
+#endif
 
 template <int VW>
 struct Stage {
@@ -251,49 +255,57 @@ __device__ __forceinline__ float solve_row(const f32x4 (&acc)[Geo<VW>::NT], cons
     float bv = lds[TRI + ic];
     __builtin_amdgcn_wave_barrier();
 
-    // 3. right-looking Cholesky fused with the forward substitution L z = b
-    float z = 0.f, myrinv = 0.f;
+    // 3. right-looking Cholesky fused with the forward substitution L z = b.  Column k of L is
+    //    broadcast through LDS (every lane reads the same 16 bytes: 4 multipliers per ds_read);
+    //    only the multiplier of the NEXT pivot column goes through v_readlane, so the
+    //    pivot-to-pivot dependency chain does not wait for an LDS round trip.  Padded indices
+    //    (>= f) carry identity rows (gram_finalize_kernel puts 1 on their diagonal) and solve to 0,
+    //    so all FPAD steps run unconditionally.
+    float *colbuf = lds + TRI + FPAD;        // 2 x 64 floats, alternating per step
+    float *zbuf = lds + TRI;                 // z_k, then reused for nothing else (b was consumed above)
+    float *rbuf = lds + TRI + FPAD + 128;    // 1 / L[k][k]
     bool bad = false;
 #pragma unroll
     for (int k = 0; k < FPAD; ++k) {
-        if (k < f) {
-            const float akk = readlane_f(a[k], k);
-            bad = bad || !(akk > 0.f);
-            const float rinv = 1.0f / sqrtf(akk);
-            const float lik = a[k] * rinv;
-            a[k] = lik;
-            const float zk = readlane_f(bv, k) * rinv;
-            if (lane == k) {
-                myrinv = rinv;
-                z = zk;
-            }
-            bv = fmaf(-lik, zk, bv);  // meaningful for lanes > k only
+        const float akk = readlane_f(a[k], k);
+        bad = bad || !(akk > 0.f);
+        const float rinv = __builtin_amdgcn_rsqf(akk);
+        const float lik = a[k] * rinv;
+        a[k] = lik;
+        if (k + 1 < FPAD) a[k + 1] = fmaf(-lik, readlane_f(lik, k + 1), a[k + 1]);
+        colbuf[(k & 1) * 64 + lane] = lik;
+        const float zk = readlane_f(bv, k) * rinv;
+        zbuf[k] = zk;   // every lane stores the same value to the same word
+        rbuf[k] = rinv;
+        bv = fmaf(-lik, zk, bv);  // meaningful for lanes > k only
 #pragma unroll
-            for (int jj = k + 1; jj < FPAD; ++jj) {
-                const float ljk = readlane_f(lik, jj);
-                a[jj] = fmaf(-lik, ljk, a[jj]);  // meaningful for lanes >= jj only
-            }
+        for (int j4 = ((k + 2) & ~3); j4 < FPAD; j4 += 4) {
+            const f32x4 l4 = *reinterpret_cast<const f32x4 *>(colbuf + (k & 1) * 64 + j4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (j4 + c > k + 1) a[j4 + c] = fmaf(-lik, l4[c], a[j4 + c]);  // meaningful for lanes >= j only
         }
     }
+    __builtin_amdgcn_wave_barrier();
 
-    // 4. L -> LDS, read back transposed: u[k] = L[k][lane]
+    // 4. L -> LDS, read back transposed: a[k] = L[k][lane]
 #pragma unroll
     for (int jj = 0; jj < FPAD; ++jj)
         if (jj <= lane && lane < FPAD) lds[rowoff + jj] = a[jj];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int jj = 0; jj < FPAD; ++jj) a[jj] = lds[jj * (jj + 1) / 2 + ic];
+    float z = zbuf[ic];
+    const float myrinv = rbuf[ic];
     __builtin_amdgcn_wave_barrier();
 
     // 5. back substitution L^T x = z
     float x = 0.f;
 #pragma unroll
     for (int k = FPAD - 1; k >= 0; --k) {
-        if (k < f) {
-            const float xk = readlane_f(z, k) * readlane_f(myrinv, k);
-            if (lane == k) x = xk;
-            if (lane < k) z = fmaf(-a[k], xk, z);
-        }
+        const float xk = readlane_f(z, k) * readlane_f(myrinv, k);
+        if (lane == k) x = xk;
+        if (lane < k) z = fmaf(-a[k], xk, z);
     }
 
     // 6. write back, |delta|
@@ -328,9 +340,9 @@ struct SweepParams {
 };
 
 template <int VW, bool VEC>
-__global__ __launch_bounds__(64) void sweep_items_kernel(const SweepParams p) {
+__global__ __launch_bounds__(64, ALS_SWEEP_WAVES) void sweep_items_kernel(const SweepParams p) {
     using G = Geo<VW>;
-    __shared__ float lds[G::TRI + G::FPAD];
+    __shared__ __attribute__((aligned(16))) float lds[G::TRI + G::FPAD + 128 + G::FPAD];
     const int lane = threadIdx.x;
     const als_item_t it = p.items[blockIdx.x];
     const int row = it.row;
@@ -346,10 +358,12 @@ __global__ __launch_bounds__(64) void sweep_items_kernel(const SweepParams p) {
 #pragma unroll
     for (int t = 0; t < VW; ++t) bacc[t] = 0.f;
 
+#ifndef ALS_ABLATE_NO_ACCUMULATE
     if (e > s) {
         accumulate_range<VW, VEC, true>(acc, bacc, p.col, p.val, s, e, p.Y, p.ldy, p.f, p.alpha, lane);
         reduce_b<VW>(bacc);
     }
+#endif
     if (it.chunk >= 0) {
         float *P = p.partials + (int64_t)it.slot * (G::PQ * 64);
 #pragma unroll
@@ -363,9 +377,18 @@ __global__ __launch_bounds__(64) void sweep_items_kernel(const SweepParams p) {
     const int64_t xr = p.row_ids ? p.row_ids[row] : (int64_t)row;
     float *xrow = p.X + xr * p.ldx;
     float d;
+#ifdef ALS_ABLATE_NO_SOLVE
+    if (e > s) {  // timing-only build: keeps the accumulators live, writes garbage
+        d = 0.f;
+        float sacc = 0.f;
+        for (int t = 0; t < G::NT; ++t) sacc += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+        if (lane < p.f) xrow[lane] = sacc + bacc[0];
+    } else {
+#else
     if (e > s) {
         d = solve_row<VW>(acc, bacc, p.gtiles, lds, p.f, xrow, p.info, lane);
-    } else {  // no entries: b = 0, so x = 0 exactly
+    } else {
+#endif  // no entries: b = 0, so x = 0 exactly
         d = 0.f;
         if (lane < p.f) {
             d = fabsf(xrow[lane]);
@@ -380,7 +403,7 @@ __global__ __launch_bounds__(64) void sweep_items_kernel(const SweepParams p) {
 template <int VW>
 __global__ __launch_bounds__(64) void sweep_long_rows_kernel(const SweepParams p) {
     using G = Geo<VW>;
-    __shared__ float lds[G::TRI + G::FPAD];
+    __shared__ __attribute__((aligned(16))) float lds[G::TRI + G::FPAD + 128 + G::FPAD];
     const int lane = threadIdx.x;
     const als_long_row_t lr = p.long_rows[blockIdx.x];
     f32x4 acc[G::NT];
@@ -464,7 +487,7 @@ __global__ void gram_finalize_kernel(const float *__restrict__ super, const int6
             }
     const int i = (lane >> 4) * 4 + r, j = lane & 15;
     const int ai = fidx<VW>(i, ta), bi = fidx<VW>(j, tb);
-    tiles_out[e] = (ai == bi && ai < f) ? v + lamb : v;
+    tiles_out[e] = (ai == bi) ? (ai < f ? v + lamb : 1.0f) : v;   // padded indices: identity rows
     if (ai < f && bi < f && (ta != tb || i >= j)) {
         gram_out[ai * f + bi] = v;
         gram_out[bi * f + ai] = v;
@@ -532,12 +555,16 @@ static int32_t gram_partials_impl(const float *Y, int64_t row_begin, int64_t row
 template <int VW>
 static int32_t half_sweep_impl(const SweepParams &p, int64_t n_rows, int64_t n_items, int64_t n_long,
                                double *absdiff_out, double *diff_partials, bool vec, hipStream_t st) {
+    hipEvent_t tap0 = g_tap_begin, tap1 = g_tap_end;
+    g_tap_begin = g_tap_end = nullptr;
     if (n_items > 0) {
+        if (tap0) ALS_HIP_CHECK(hipEventRecord(tap0, st));
         if (vec)
             hipLaunchKernelGGL((sweep_items_kernel<VW, true>), dim3((unsigned)n_items), dim3(64), 0, st, p);
         else
             hipLaunchKernelGGL((sweep_items_kernel<VW, false>), dim3((unsigned)n_items), dim3(64), 0, st, p);
         ALS_HIP_CHECK(hipGetLastError());
+        if (tap1) ALS_HIP_CHECK(hipEventRecord(tap1, st));
     }
     if (n_long > 0) {
         hipLaunchKernelGGL(sweep_long_rows_kernel<VW>, dim3((unsigned)n_long), dim3(64), 0, st, p);
@@ -561,6 +588,13 @@ static int32_t half_sweep_impl(const SweepParams &p, int64_t n_rows, int64_t n_i
 extern "C" {
 
 const char *als_last_error_string(void) { return g_err; }
+
+int32_t als_profile_tap_next_sweep(void *ev_begin, void *ev_end) {
+    if ((ev_begin == nullptr) != (ev_end == nullptr)) return fail(ALS_ERR_INVALID_ARG, "pass both events or neither");
+    g_tap_begin = (hipEvent_t)ev_begin;
+    g_tap_end = (hipEvent_t)ev_end;
+    return ALS_OK;
+}
 int32_t als_abi_version(void) { return 1; }
 
 // ----------------------------------------------------------------------------- plan

@@ -67,31 +67,38 @@ class DeviceCSR:
     row schedule.  `row_ids`, if given, maps CSR row u to the factor row it updates."""
 
     def __init__(self, indptr, indices, data, shape, device, chunk_nnz=_lib.DEFAULT_CHUNK_NNZ, row_ids=None):
-        indptr = np.ascontiguousarray(indptr, dtype=np.int64)
-        indices = np.ascontiguousarray(indices, dtype=np.int32)
-        data = np.ascontiguousarray(data, dtype=np.float32)
+        """indptr / indices / data: numpy arrays or torch tensors (host or device)."""
+        dev = torch.empty(0, device=device).device           # normalised ("cuda" -> "cuda:0")
         n_rows, n_cols = int(shape[0]), int(shape[1])
-        if indptr.shape[0] != n_rows + 1 or indptr[0] != 0 or indptr[-1] != indices.shape[0] \
-                or indices.shape[0] != data.shape[0]:
-            raise ValueError("inconsistent CSR arrays")
+
+        def as_dev(a, dtype):
+            t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+            return t.to(device=dev, dtype=dtype).contiguous()
+
+        rowptr = as_dev(indptr, torch.int64)
+        col = as_dev(indices, torch.int32)
+        val = as_dev(data, torch.float32)
+        host_ptr = rowptr.cpu().numpy()
         if n_rows < 1:
             raise ValueError("CSR needs at least one row")
-        if np.any(np.diff(indptr) < 0):
+        if host_ptr.shape[0] != n_rows + 1 or host_ptr[0] != 0 or host_ptr[-1] != col.shape[0] \
+                or col.shape[0] != val.shape[0] or col.dim() != 1:
+            raise ValueError("inconsistent CSR arrays")
+        if np.any(np.diff(host_ptr) < 0):
             raise ValueError("indptr must be non-decreasing")
-        if indices.size and (indices.min() < 0 or indices.max() >= n_cols):
+        if col.numel() and (int(col.min()) < 0 or int(col.max()) >= n_cols):
             raise ValueError("column index out of range [0, %d)" % n_cols)
         self.shape = (n_rows, n_cols)
-        self.nnz = int(indices.shape[0])
+        self.nnz = int(col.shape[0])
         self.chunk_nnz = int(chunk_nnz)
-        self.device = torch.device(device)
-        items, long_rows, self.n_slots = build_plan(indptr, chunk_nnz)
+        self.device = dev
+        items, long_rows, self.n_slots = build_plan(host_ptr, chunk_nnz)
         self.n_items, self.n_long = items.shape[0], long_rows.shape[0]
-        dev = self.device
-        self.rowptr = torch.from_numpy(indptr).to(dev)
-        self.device = dev = self.rowptr.device        # normalised ("cuda" -> "cuda:0")
-        # one spare element keeps the pointers non-null for a matrix without entries
-        self.col = torch.from_numpy(np.concatenate([indices, np.zeros(1, np.int32)])).to(dev)
-        self.val = torch.from_numpy(np.concatenate([data, np.zeros(1, np.float32)])).to(dev)
+        self.rowptr = rowptr
+        if self.nnz == 0:   # keep the pointers non-null for a matrix without entries
+            col = torch.zeros(1, dtype=torch.int32, device=dev)
+            val = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.col, self.val = col, val
         self.items = torch.from_numpy(items).to(dev)
         self.long_rows = torch.from_numpy(long_rows).to(dev) if self.n_long else None
         self.row_ids = None
