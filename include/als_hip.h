@@ -135,6 +135,34 @@ int32_t als_half_sweep_csr_f32(const int64_t *rowptr, const int32_t *col, const 
                                double *absdiff_out, int32_t *info_out, void *workspace, size_t ws_bytes,
                                void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * Scoring - replaces ALSTrainer.predict + SimpleMFRecAlgo.recommend
+ * (reclibwh/core/ALS.py:359-362, reclibwh/core/RecAlgos.py:20-32) and
+ * cosine_similarity_tf / SimpleMFSimAlgo.similar (RecAlgos.py:38-73).
+ *
+ * als_scores_f32        scores[u][i] = <X[user_ids[u]], Y[i]> for u < nu, i < M (user_ids NULL:
+ *                       rows 0..nu-1 of X).  scores is [nu, lds] row major, lds >= M.
+ * als_topk_rows_f32     per row of `scores`, the k largest entries in descending order, ties by
+ *                       ascending column (the reference does a full numpy argsort of every row,
+ *                       RecAlgos.py:32; its consumers keep the first 200).  If ex_rowptr/ex_col
+ *                       (a CSR with n_rows rows) are given, those columns of each row are set to
+ *                       -inf first, in place (the "drop rated items" filter of
+ *                       reclibwh/serving/RecommenderService.py:16-29).  1 <= k <= min(1024, M).
+ * als_predict_pairs_f32 out[p] = <X[u[p]], Y[i[p]]> (the ALS Keras model's output, model
+ *                       template ALS.json.template:38-43).
+ * als_normalize_rows_f32 out[r] = E[r] / ||E[r]||_2, rows of zero norm become 0
+ *                       (RecAlgos.py:45-50); out may alias E.
+ * All pointers are [device]; all work is enqueued on `stream`.
+ * ------------------------------------------------------------------------------------ */
+int32_t als_scores_f32(const float *X, int64_t ldx, const int64_t *user_ids, int64_t nu, const float *Y, int64_t ldy,
+                       int64_t M, int32_t f, float *scores, int64_t lds, void *stream);
+int32_t als_topk_rows_f32(float *scores, int64_t lds, int64_t n_rows, int64_t M, const int64_t *ex_rowptr,
+                          const int32_t *ex_col, int32_t k, int32_t *idx_out, float *score_out, void *stream);
+int32_t als_predict_pairs_f32(const float *X, int64_t ldx, const float *Y, int64_t ldy, const int64_t *u,
+                              const int64_t *i, int64_t n, int32_t f, float *out, void *stream);
+int32_t als_normalize_rows_f32(const float *E, int64_t lde, int64_t n, int32_t f, float *out, int64_t ldo,
+                               void *stream);
+
 /* Profiling tap (no reference counterpart; for benchmarks): the next
  * als_half_sweep_csr_f32 call made by the calling thread records the two hipEvent_t
  * handles on its stream immediately before and after its per-row gather/accumulate

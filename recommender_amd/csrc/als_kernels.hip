@@ -26,6 +26,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "als_hip.h"
@@ -85,28 +86,38 @@ struct Stage {
 };
 
 // ----------------------------------------------------------------------------- loads
-// Elements fidx(j, 0..VW-1) of the factor row at rowp; elements >= f read as 0.
-template <int VW, bool VEC>
-__device__ __forceinline__ void load_vec(const float *__restrict__ rowp, int f, int j, float (&v)[VW]) {
+// Vector unit of the factor loads: VW floats for VW <= 4, 4 floats (two loads) for VW = 8.
+template <int VW>
+struct VecUnit {
+    static constexpr int W = VW >= 4 ? 4 : VW;
+};
+
+// Elements fidx(j, 0..VW-1) of one factor row; elements >= f read as 0 (not needed when FULL,
+// i.e. f == 16*VW).  VEC: `off` is the row's offset in vector units (row * ld / W) and the row is
+// fetched with 8- or 16-byte loads; otherwise `off` is the row index and elements are loaded one
+// by one (any f, any ld, any alignment).
+template <int VW, bool VEC, bool FULL>
+__device__ __forceinline__ void load_vec(const float *__restrict__ Y, const uint32_t off, const int64_t ld,
+                                         const int f, const int j, float (&v)[VW]) {
     if constexpr (!VEC || VW == 1) {
+        const float *rowp = Y + (int64_t)off * ld;
 #pragma unroll
         for (int t = 0; t < VW; ++t) {
             const int idx = fidx<VW>(j, t);
-            const bool ok = idx < f;
+            const bool ok = FULL || idx < f;
             const float x = rowp[ok ? idx : 0];
             v[t] = ok ? x : 0.f;
         }
     } else if constexpr (VW == 2) {
-        const bool ok = 2 * j < f;
-        const f32x2 x = *reinterpret_cast<const f32x2 *>(rowp + (ok ? 2 * j : 0));
+        const bool ok = FULL || 2 * j < f;
+        const f32x2 x = reinterpret_cast<const f32x2 *>(Y)[off + (ok ? j : 0)];
         v[0] = ok ? x.x : 0.f;
         v[1] = ok ? x.y : 0.f;
     } else {
 #pragma unroll
         for (int h = 0; h < VW / 4; ++h) {
-            const int idx = 64 * h + 4 * j;
-            const bool ok = idx < f;
-            const f32x4 x = *reinterpret_cast<const f32x4 *>(rowp + (ok ? idx : 0));
+            const bool ok = FULL || 64 * h + 4 * j < f;
+            const f32x4 x = reinterpret_cast<const f32x4 *>(Y)[off + (ok ? 16 * h + j : 0)];
             v[4 * h + 0] = ok ? x.x : 0.f;
             v[4 * h + 1] = ok ? x.y : 0.f;
             v[4 * h + 2] = ok ? x.z : 0.f;
@@ -116,22 +127,20 @@ __device__ __forceinline__ void load_vec(const float *__restrict__ rowp, int f, 
 }
 
 // ----------------------------------------------------------------------------- accumulate
-// Issue the gathers of group g (16 entries) of the 64-entry chunk whose column indices and
-// ratings sit one per lane in (cur_c, cur_r).
-template <int VW, bool VEC>
-__device__ __forceinline__ void issue(Stage<VW> &st, const int g, const int cur_c, const float cur_r,
-                                      const float *__restrict__ Y, const int64_t ld, const int f, const float alpha,
+// Issue the gathers of group g (16 entries) of the 64-entry chunk whose row offsets and weights
+// sit one per lane in (cur_off, cur_w, cur_cw).
+template <int VW, bool VEC, bool FULL>
+__device__ __forceinline__ void issue(Stage<VW> &st, const int g, const uint32_t cur_off, const float cur_w,
+                                      const float cur_cw, const float *__restrict__ Y, const int64_t ld, const int f,
                                       const int lane) {
     const int grp = lane >> 4, j = lane & 15;
 #pragma unroll
     for (int s = 0; s < GS; ++s) {
         const int src = g * (GS * 4) + s * 4 + grp;
-        const int cj = __shfl(cur_c, src);
-        const float rj = __shfl(cur_r, src);
-        const float w = alpha * rj;
-        st.w[s] = w;
-        st.cw[s] = (rj != 0.f) ? 1.f + w : 0.f;
-        load_vec<VW, VEC>(Y + (int64_t)cj * ld, f, j, st.v[s]);
+        const uint32_t o = (uint32_t)__shfl((int)cur_off, src);
+        st.w[s] = __shfl(cur_w, src);
+        st.cw[s] = __shfl(cur_cw, src);
+        load_vec<VW, VEC, FULL>(Y, o, ld, f, j, st.v[s]);
     }
 }
 
@@ -153,47 +162,53 @@ __device__ __forceinline__ void compute(const Stage<VW> &st, f32x4 (&acc)[Geo<VW
 }
 
 // acc += sum_{e in [s, e)} w_e y_e y_e^T, bacc += sum c_e y_e over CSR entries [s, e) (GATHER)
-// or over the dense rows [s, e) of Y with w = 1 (!GATHER, the Gram).  s, e are wave uniform, e > s.
-template <int VW, bool VEC, bool GATHER>
+// with w = alpha r, c = 1 + alpha r (0 for a stored zero), or over the dense rows [s, e) of Y with
+// w = 1 (!GATHER, the Gram).  s, e are wave uniform, e > s.
+template <int VW, bool VEC, bool FULL, bool GATHER>
 __device__ __forceinline__ void accumulate_range(f32x4 (&acc)[Geo<VW>::NT], float (&bacc)[VW],
                                                  const int32_t *__restrict__ col, const float *__restrict__ val,
                                                  const int64_t s, const int64_t e, const float *__restrict__ Y,
                                                  const int64_t ld, const int f, const float alpha, const int lane) {
     Stage<VW> A, B;
-    int cur_c, nxt_c = 0;
-    float cur_r, nxt_r = 0.f;
-    auto load_chunk = [&](const int64_t base, int &c, float &r) {
+    uint32_t cur_off, nxt_off = 0;
+    float cur_w, cur_cw, nxt_w = 0.f, nxt_cw = 0.f;
+    const uint32_t ldu = VEC ? (uint32_t)(ld / VecUnit<VW>::W) : 1u;   // row pitch in vector units
+    auto load_chunk = [&](const int64_t base, uint32_t &off, float &w, float &cw) {
         const int64_t idx = base + lane;
         const bool ok = idx < e;
         if constexpr (GATHER) {
             const int64_t ii = ok ? idx : s;
             const int cc = col[ii];
             const float rr = val[ii];
-            c = ok ? cc : 0;
-            r = ok ? rr : 0.f;
+            const float ww = alpha * rr;
+            off = ok ? (uint32_t)cc * ldu : 0u;
+            w = ok ? ww : 0.f;
+            cw = (ok && rr != 0.f) ? 1.f + ww : 0.f;
         } else {
-            c = ok ? (int)idx : 0;
-            r = ok ? 1.f : 0.f;
+            off = ok ? (uint32_t)idx * ldu : 0u;
+            w = ok ? 1.f : 0.f;
+            cw = 0.f;
         }
     };
-    load_chunk(s, cur_c, cur_r);
-    issue<VW, VEC>(A, 0, cur_c, cur_r, Y, ld, f, alpha, lane);
+    load_chunk(s, cur_off, cur_w, cur_cw);
+    issue<VW, VEC, FULL>(A, 0, cur_off, cur_w, cur_cw, Y, ld, f, lane);
     for (int64_t base = s; base < e; base += 64) {
         const int64_t nb = base + 64;
         const bool more = nb < e;
-        if (more) load_chunk(nb, nxt_c, nxt_r);
+        if (more) load_chunk(nb, nxt_off, nxt_w, nxt_cw);
         const int rem = more ? 64 : (int)(e - base);
         const int ng = (rem + 15) >> 4;
-        if (ng > 1) issue<VW, VEC>(B, 1, cur_c, cur_r, Y, ld, f, alpha, lane);
+        if (ng > 1) issue<VW, VEC, FULL>(B, 1, cur_off, cur_w, cur_cw, Y, ld, f, lane);
         compute<VW, GATHER>(A, acc, bacc);
-        if (ng > 2) issue<VW, VEC>(A, 2, cur_c, cur_r, Y, ld, f, alpha, lane);
+        if (ng > 2) issue<VW, VEC, FULL>(A, 2, cur_off, cur_w, cur_cw, Y, ld, f, lane);
         if (ng > 1) compute<VW, GATHER>(B, acc, bacc);
-        if (ng > 3) issue<VW, VEC>(B, 3, cur_c, cur_r, Y, ld, f, alpha, lane);
+        if (ng > 3) issue<VW, VEC, FULL>(B, 3, cur_off, cur_w, cur_cw, Y, ld, f, lane);
         if (ng > 2) compute<VW, GATHER>(A, acc, bacc);
         if (more) {
-            cur_c = nxt_c;
-            cur_r = nxt_r;
-            issue<VW, VEC>(A, 0, cur_c, cur_r, Y, ld, f, alpha, lane);
+            cur_off = nxt_off;
+            cur_w = nxt_w;
+            cur_cw = nxt_cw;
+            issue<VW, VEC, FULL>(A, 0, cur_off, cur_w, cur_cw, Y, ld, f, lane);
         }
         if (ng > 3) compute<VW, GATHER>(B, acc, bacc);
     }
@@ -212,6 +227,51 @@ __device__ __forceinline__ void reduce_b(float (&bacc)[VW]) {
 // ----------------------------------------------------------------------------- solve
 __device__ __forceinline__ float readlane_f(const float x, const int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
+}
+
+// One step of the right-looking Cholesky (K is a compile-time constant so that every register
+// index is static; the steps are expanded with an index sequence, not a loop the optimizer may
+// decline to unroll).
+template <int FPAD, int K>
+__device__ __forceinline__ void chol_step(float (&a)[FPAD], float &bv, bool &bad, float *colbuf, float *zbuf,
+                                          float *rbuf, const int lane) {
+    const float akk = readlane_f(a[K], K);
+    bad = bad || !(akk > 0.f);
+    const float rinv = __builtin_amdgcn_rsqf(akk);
+    const float lik = a[K] * rinv;
+    a[K] = lik;
+    if constexpr (K + 1 < FPAD) a[K + 1] = fmaf(-lik, readlane_f(lik, K + 1), a[K + 1]);
+    colbuf[(K & 1) * 64 + lane] = lik;
+    const float zk = readlane_f(bv, K) * rinv;
+    zbuf[K] = zk;  // every lane stores the same value to the same word
+    rbuf[K] = rinv;
+    bv = fmaf(-lik, zk, bv);  // meaningful for lanes > K only
+#pragma unroll
+    for (int j4 = ((K + 2) & ~3); j4 < FPAD; j4 += 4) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4 *>(colbuf + (K & 1) * 64 + j4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (j4 + c > K + 1) a[j4 + c] = fmaf(-lik, l4[c], a[j4 + c]);  // meaningful for lanes >= j only
+    }
+}
+template <int FPAD, int... Ks>
+__device__ __forceinline__ void chol_all(float (&a)[FPAD], float &bv, bool &bad, float *colbuf, float *zbuf,
+                                         float *rbuf, const int lane, std::integer_sequence<int, Ks...>) {
+    (chol_step<FPAD, Ks>(a, bv, bad, colbuf, zbuf, rbuf, lane), ...);
+}
+// Step of the back substitution L^T x = z for pivot KK = FPAD-1-K (a[k] holds L[k][lane]).
+template <int FPAD, int K>
+__device__ __forceinline__ void backsub_step(const float (&a)[FPAD], float &z, float &x, const float myrinv,
+                                             const int lane) {
+    constexpr int KK = FPAD - 1 - K;
+    const float xk = readlane_f(z, KK) * readlane_f(myrinv, KK);
+    if (lane == KK) x = xk;
+    if (lane < KK) z = fmaf(-a[KK], xk, z);
+}
+template <int FPAD, int... Ks>
+__device__ __forceinline__ void backsub_all(const float (&a)[FPAD], float &z, float &x, const float myrinv,
+                                            const int lane, std::integer_sequence<int, Ks...>) {
+    (backsub_step<FPAD, Ks>(a, z, x, myrinv, lane), ...);
 }
 
 // Solve (acc + gram_tiles) x = b for one row (f <= 64) and write x.  `lds` is this wave's
@@ -265,27 +325,7 @@ __device__ __forceinline__ float solve_row(const f32x4 (&acc)[Geo<VW>::NT], cons
     float *zbuf = lds + TRI;                 // z_k, then reused for nothing else (b was consumed above)
     float *rbuf = lds + TRI + FPAD + 128;    // 1 / L[k][k]
     bool bad = false;
-#pragma unroll
-    for (int k = 0; k < FPAD; ++k) {
-        const float akk = readlane_f(a[k], k);
-        bad = bad || !(akk > 0.f);
-        const float rinv = __builtin_amdgcn_rsqf(akk);
-        const float lik = a[k] * rinv;
-        a[k] = lik;
-        if (k + 1 < FPAD) a[k + 1] = fmaf(-lik, readlane_f(lik, k + 1), a[k + 1]);
-        colbuf[(k & 1) * 64 + lane] = lik;
-        const float zk = readlane_f(bv, k) * rinv;
-        zbuf[k] = zk;   // every lane stores the same value to the same word
-        rbuf[k] = rinv;
-        bv = fmaf(-lik, zk, bv);  // meaningful for lanes > k only
-#pragma unroll
-        for (int j4 = ((k + 2) & ~3); j4 < FPAD; j4 += 4) {
-            const f32x4 l4 = *reinterpret_cast<const f32x4 *>(colbuf + (k & 1) * 64 + j4);
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (j4 + c > k + 1) a[j4 + c] = fmaf(-lik, l4[c], a[j4 + c]);  // meaningful for lanes >= j only
-        }
-    }
+    chol_all<FPAD>(a, bv, bad, colbuf, zbuf, rbuf, lane, std::make_integer_sequence<int, FPAD>{});
     __builtin_amdgcn_wave_barrier();
 
     // 4. L -> LDS, read back transposed: a[k] = L[k][lane]
@@ -301,12 +341,7 @@ __device__ __forceinline__ float solve_row(const f32x4 (&acc)[Geo<VW>::NT], cons
 
     // 5. back substitution L^T x = z
     float x = 0.f;
-#pragma unroll
-    for (int k = FPAD - 1; k >= 0; --k) {
-        const float xk = readlane_f(z, k) * readlane_f(myrinv, k);
-        if (lane == k) x = xk;
-        if (lane < k) z = fmaf(-a[k], xk, z);
-    }
+    backsub_all<FPAD>(a, z, x, myrinv, lane, std::make_integer_sequence<int, FPAD>{});
 
     // 6. write back, |delta|
     float d = 0.f;
@@ -339,7 +374,7 @@ struct SweepParams {
     float alpha;
 };
 
-template <int VW, bool VEC>
+template <int VW, bool VEC, bool FULL>
 __global__ __launch_bounds__(64, ALS_SWEEP_WAVES) void sweep_items_kernel(const SweepParams p) {
     using G = Geo<VW>;
     __shared__ __attribute__((aligned(16))) float lds[G::TRI + G::FPAD + 128 + G::FPAD];
@@ -360,7 +395,7 @@ __global__ __launch_bounds__(64, ALS_SWEEP_WAVES) void sweep_items_kernel(const 
 
 #ifndef ALS_ABLATE_NO_ACCUMULATE
     if (e > s) {
-        accumulate_range<VW, VEC, true>(acc, bacc, p.col, p.val, s, e, p.Y, p.ldy, p.f, p.alpha, lane);
+        accumulate_range<VW, VEC, FULL, true>(acc, bacc, p.col, p.val, s, e, p.Y, p.ldy, p.f, p.alpha, lane);
         reduce_b<VW>(bacc);
     }
 #endif
@@ -431,7 +466,7 @@ __global__ __launch_bounds__(64) void sweep_long_rows_kernel(const SweepParams p
 }
 
 // Gram, level 1: one wave per ALS_GRAM_CHUNK_ROWS rows of Y[row0 .. n_end).
-template <int VW, bool VEC>
+template <int VW, bool VEC, bool FULL>
 __global__ __launch_bounds__(64) void gram_chunk_kernel(const float *__restrict__ Y, const int64_t row0,
                                                        const int64_t n_end, const int64_t ld, const int f,
                                                        float *__restrict__ out) {
@@ -445,7 +480,7 @@ __global__ __launch_bounds__(64) void gram_chunk_kernel(const float *__restrict_
     for (int t = 0; t < G::NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < VW; ++t) bacc[t] = 0.f;
-    if (e > s) accumulate_range<VW, VEC, false>(acc, bacc, nullptr, nullptr, s, e, Y, ld, f, 1.0f, lane);
+    if (e > s) accumulate_range<VW, VEC, FULL, false>(acc, bacc, nullptr, nullptr, s, e, Y, ld, f, 1.0f, lane);
     float *P = out + (int64_t)blockIdx.x * (G::TQ * 64);
 #pragma unroll
     for (int t = 0; t < G::NT; ++t)
@@ -521,11 +556,13 @@ inline int tq_for(int f) {
 }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-inline bool vec_ok(const float *p, int64_t ld, int f) {
+// Vector loads need whole vectors inside a row, an aligned base and row offsets (in vector
+// units) that fit 32 bits; otherwise the element-wise path is used.
+inline bool vec_ok(const float *p, int64_t ld, int f, int64_t n_rows) {
     const int vw = vw_for(f);
-    if (vw == 1) return true;
+    if (vw == 1) return false;
     const int w = vw >= 4 ? 4 : 2;
-    return (f % w == 0) && (ld % w == 0) && ((uintptr_t)p % (4 * w) == 0);
+    return (f % w == 0) && (ld % w == 0) && ((uintptr_t)p % (4 * w) == 0) && (n_rows * (ld / w) < 0xffffffffLL);
 }
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -538,12 +575,13 @@ static int32_t gram_partials_impl(const float *Y, int64_t row_begin, int64_t row
     const int64_t n_chunks = ceil_div(n, ALS_GRAM_CHUNK_ROWS);
     const int64_t n_super = ceil_div(n, ALS_GRAM_SUPER_ROWS);
     float *chunks = (float *)workspace;
-    if (vec_ok(Y, ldy, f))
-        hipLaunchKernelGGL((gram_chunk_kernel<VW, true>), dim3((unsigned)n_chunks), dim3(64), 0, st, Y, row_begin, row_end,
-                           ldy, f, chunks);
+    const dim3 grid((unsigned)n_chunks), block(64);
+    if (vec_ok(Y, ldy, f, row_end) && f == G::FPAD)
+        hipLaunchKernelGGL((gram_chunk_kernel<VW, true, true>), grid, block, 0, st, Y, row_begin, row_end, ldy, f, chunks);
+    else if (vec_ok(Y, ldy, f, row_end))
+        hipLaunchKernelGGL((gram_chunk_kernel<VW, true, false>), grid, block, 0, st, Y, row_begin, row_end, ldy, f, chunks);
     else
-        hipLaunchKernelGGL((gram_chunk_kernel<VW, false>), dim3((unsigned)n_chunks), dim3(64), 0, st, Y, row_begin,
-                           row_end, ldy, f, chunks);
+        hipLaunchKernelGGL((gram_chunk_kernel<VW, false, false>), grid, block, 0, st, Y, row_begin, row_end, ldy, f, chunks);
     ALS_HIP_CHECK(hipGetLastError());
     const int elems = G::TQ * 64;
     hipLaunchKernelGGL(sum_groups_kernel, dim3((elems + 255) / 256, (unsigned)n_super), dim3(256), 0, st, chunks, n_chunks,
@@ -559,10 +597,13 @@ static int32_t half_sweep_impl(const SweepParams &p, int64_t n_rows, int64_t n_i
     g_tap_begin = g_tap_end = nullptr;
     if (n_items > 0) {
         if (tap0) ALS_HIP_CHECK(hipEventRecord(tap0, st));
-        if (vec)
-            hipLaunchKernelGGL((sweep_items_kernel<VW, true>), dim3((unsigned)n_items), dim3(64), 0, st, p);
+        const dim3 grid((unsigned)n_items), block(64);
+        if (vec && p.f == Geo<VW>::FPAD)
+            hipLaunchKernelGGL((sweep_items_kernel<VW, true, true>), grid, block, 0, st, p);
+        else if (vec)
+            hipLaunchKernelGGL((sweep_items_kernel<VW, true, false>), grid, block, 0, st, p);
         else
-            hipLaunchKernelGGL((sweep_items_kernel<VW, false>), dim3((unsigned)n_items), dim3(64), 0, st, p);
+            hipLaunchKernelGGL((sweep_items_kernel<VW, false, false>), grid, block, 0, st, p);
         ALS_HIP_CHECK(hipGetLastError());
         if (tap1) ALS_HIP_CHECK(hipEventRecord(tap1, st));
     }
@@ -583,6 +624,15 @@ static int32_t half_sweep_impl(const SweepParams &p, int64_t n_rows, int64_t n_i
 }
 
 }  // namespace
+
+// shared with als_scoring.hip: records the calling thread's last error and returns `code`
+int als_fail_(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
 
 // ============================================================================= C ABI
 extern "C" {
@@ -766,7 +816,7 @@ int32_t als_half_sweep_csr_f32(const int64_t *rowptr, const int32_t *col, const 
     p.rowdiff = (float *)ws; ws += align_up((size_t)n_rows * sizeof(float), 256);
     double *diff_partials = (double *)ws;
     p.info = info_out; p.ldy = ldy; p.ldx = ldx; p.f = f; p.chunk_nnz = chunk_nnz; p.alpha = alpha;
-    const bool vec = vec_ok(Yopp, ldy, f);
+    const bool vec = vec_ok(Yopp, ldy, f, n_opp);
     hipStream_t st = (hipStream_t)stream;
     switch (vw) {
         case 1: return half_sweep_impl<1>(p, n_rows, n_items, n_long, absdiff_out, diff_partials, vec, st);

@@ -225,3 +225,116 @@ def half_sweep(csr, Yopp, gram_cache, Xown, alpha, absdiff=None, info=None):
             _ptr(gram_cache.tiles), f, float(alpha), _ptr(Xown), ldx, _ptr(absdiff), _ptr(info), _ptr(ws),
             ws.numel(), _stream()), "als_half_sweep_csr_f32")
     return absdiff
+
+
+# ----------------------------------------------------------------------------- scoring
+def scores(X, Y, user_ids=None, M=None, out=None):
+    """scores[u, i] = <X[user_ids[u]], Y[i]> for i < M: the [nu, M] matrix that
+    SimpleMFRecAlgo.recommend builds pair by pair (reclibwh/core/RecAlgos.py:20-30)."""
+    ldx = _factor_ld(X, "X")
+    ldy = _factor_ld(Y, "Y")
+    f = X.shape[1]
+    if Y.shape[1] != f:
+        raise ValueError("factor counts differ")
+    M = Y.shape[0] if M is None else int(M)
+    if not (1 <= M <= Y.shape[0]):
+        raise ValueError("M out of range")
+    if user_ids is not None:
+        _need(user_ids, torch.int64, "user_ids", 1)
+        nu = user_ids.shape[0]
+        if nu and (int(user_ids.min()) < 0 or int(user_ids.max()) >= X.shape[0]):
+            raise ValueError("user id out of range")
+    else:
+        nu = X.shape[0]
+    if nu < 1:
+        raise ValueError("no users")
+    if out is None:
+        out = torch.empty((nu, M), dtype=torch.float32, device=X.device)
+    _need(out, torch.float32, "out", 2)
+    if out.shape[0] < nu or out.shape[1] < M or out.stride(1) != 1:
+        raise ValueError("out too small or not row-major")
+    with torch.cuda.device(X.device):
+        check(lib.als_scores_f32(_ptr(X), ldx, _ptr(user_ids), nu, _ptr(Y), ldy, M, f, _ptr(out), out.stride(0),
+                                 _stream()), "als_scores_f32")
+    return out[:nu, :M]
+
+
+def topk_rows(score_rows, k, exclude=None):
+    """Per row: the k largest scores, descending, ties by ascending column.  `exclude` =
+    (rowptr int64 [n_rows+1], col int32) device tensors: columns forced to -inf first (the score
+    rows are modified in place).  Returns (idx int32 [n, k], values float32 [n, k])."""
+    _need(score_rows, torch.float32, "score_rows", 2)
+    if score_rows.stride(1) != 1:
+        raise ValueError("score rows must have unit inner stride")
+    n, M = score_rows.shape
+    k = int(k)
+    if not (1 <= k <= min(1024, M)):
+        raise ValueError("k must be in [1, min(1024, M)]")
+    ex_ptr = ex_col = None
+    if exclude is not None:
+        ex_ptr, ex_col = exclude
+        _need(ex_ptr, torch.int64, "exclude rowptr", 1)
+        _need(ex_col, torch.int32, "exclude col", 1)
+        if ex_ptr.shape[0] != n + 1:
+            raise ValueError("exclude rowptr must have n_rows + 1 entries")
+    idx = torch.empty((n, k), dtype=torch.int32, device=score_rows.device)
+    val = torch.empty((n, k), dtype=torch.float32, device=score_rows.device)
+    with torch.cuda.device(score_rows.device):
+        check(lib.als_topk_rows_f32(_ptr(score_rows), score_rows.stride(0), n, M, _ptr(ex_ptr), _ptr(ex_col), k,
+                                    _ptr(idx), _ptr(val), _stream()), "als_topk_rows_f32")
+    return idx, val
+
+
+def predict_pairs(X, Y, u, i):
+    """out[p] = <X[u[p]], Y[i[p]]>: the ALS model's output for explicit (user, item) pairs
+    (reclibwh/core/ALS.py:359-362)."""
+    ldx = _factor_ld(X, "X"); ldy = _factor_ld(Y, "Y")
+    _need(u, torch.int64, "u", 1); _need(i, torch.int64, "i", 1)
+    if u.shape != i.shape or u.numel() < 1:
+        raise ValueError("u and i must be equally long, non-empty")
+    if int(u.min()) < 0 or int(u.max()) >= X.shape[0] or int(i.min()) < 0 or int(i.max()) >= Y.shape[0]:
+        raise ValueError("index out of range")
+    out = torch.empty(u.shape[0], dtype=torch.float32, device=X.device)
+    with torch.cuda.device(X.device):
+        check(lib.als_predict_pairs_f32(_ptr(X), ldx, _ptr(Y), ldy, _ptr(u), _ptr(i), u.shape[0], X.shape[1],
+                                        _ptr(out), _stream()), "als_predict_pairs_f32")
+    return out
+
+
+def normalize_rows(E, out=None):
+    """Rows scaled to unit 2-norm, zero rows stay zero (reclibwh/core/RecAlgos.py:45-50)."""
+    lde = _factor_ld(E, "E")
+    if out is None:
+        out = torch.empty_like(E)
+    ldo = _factor_ld(out, "out")
+    with torch.cuda.device(E.device):
+        check(lib.als_normalize_rows_f32(_ptr(E), lde, E.shape[0], E.shape[1], _ptr(out), ldo, _stream()),
+              "als_normalize_rows_f32")
+    return out
+
+
+def recommend_topk(X, Y, users, k, M=None, exclude_csr=None, block_users=1024):
+    """Top-k items for `users` (int64 device tensor) without materialising more than
+    block_users x M scores.  exclude_csr: optional (rowptr, col) HOST numpy CSR over ALL users
+    whose columns are filtered per user.  Returns (idx int32 [nu, k], scores [nu, k])."""
+    M = Y.shape[0] if M is None else int(M)
+    nu = users.shape[0]
+    idx = torch.empty((nu, k), dtype=torch.int32, device=X.device)
+    val = torch.empty((nu, k), dtype=torch.float32, device=X.device)
+    buf = torch.empty((min(block_users, nu), M), dtype=torch.float32, device=X.device)
+    users_host = users.cpu().numpy() if exclude_csr is not None else None
+    for s in range(0, nu, block_users):
+        e = min(nu, s + block_users)
+        sc = scores(X, Y, users[s:e], M, out=buf)
+        ex = None
+        if exclude_csr is not None:
+            ptr, col = exclude_csr
+            lens = (ptr[users_host[s:e] + 1] - ptr[users_host[s:e]]).astype(np.int64)
+            p = np.zeros(e - s + 1, dtype=np.int64); np.cumsum(lens, out=p[1:])
+            cols = np.concatenate([col[ptr[u]:ptr[u + 1]] for u in users_host[s:e]]) if p[-1] else np.zeros(0, np.int32)
+            ex = (torch.from_numpy(p).to(X.device),
+                  torch.from_numpy(np.ascontiguousarray(cols, dtype=np.int32)).to(X.device)
+                  if p[-1] else torch.zeros(1, dtype=torch.int32, device=X.device))
+        i_, v_ = topk_rows(sc, k, ex)
+        idx[s:e] = i_; val[s:e] = v_
+    return idx, val

@@ -1,0 +1,246 @@
+"""RecommenderALS - the drop-in facade for the implicit-ALS path of reclibwh.
+
+The reference documents `reclibwh.recommender.recommenderALS.RecommenderALS` (README.md:71,138)
+and uses it in notebooks/ego_graph_viz.ipynb (cells 7, 9, 15), but the class itself is not in
+the repository.  Its surface is therefore taken from the sibling RecommenderMF usage block
+(README.md:26-42: constructor(mode, n_users, n_items, <algo>_kwargs, model_path),
+input_data(d), train(), save(path)) and from the notebook (mode='predict', predict(u, i),
+similar_to([item])); numerics follow reclibwh/core/ALS.py (ALSRef / ALSTrainer).
+
+Saved layout (ALSRef.save, ALS.py:143-149): <path>/X.npy and <path>/Y.npy, float64 row-major
+[n_users, f] and [n_items, f] (the P / Q factors), plus algorithm_config.json
+({epochs, start_epoch, alpha, lamb}, ALS.py:264-283) and eval.csv (epoch,score;
+EvalProto.py:93-94) when evaluation ran.
+"""
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import metrics, ops
+from .als import ALSEngine, init_factors
+
+DEFAULTS = dict(f=20,           # ALS.json.template:26 (the reference's layer width)
+                lamb=1e-06,     # ALS.py:42, ALS.py:264
+                alpha=40.0,     # ALS.py:42, ALS.py:264
+                epochs=10,      # ALSRef steps (ALS.py:42)
+                init="ref",     # "ref": ALS.py:59-65, "tf": ALS.py:255-257
+                seed=42,
+                phantom_rows=0,     # >0: TensorFlow-path layout, layers get extra never-updated rows
+                                    # that still enter the Gram (ALS.py:243, ALS.py:456)
+                chunk_nnz=2048,
+                med_score=3.0,      # ALS.py:402
+                eval_lim=200)       # EvalProto.py:22
+
+
+class RecommenderALS:
+    def __init__(self, mode="train", n_users=None, n_items=None, als_kwargs=None, model_path=None, device=None):
+        if mode not in ("train", "predict"):
+            raise ValueError("mode must be 'train' or 'predict'")
+        self.mode = mode
+        self.model_path = model_path
+        kw = dict(DEFAULTS)
+        for k, v in (als_kwargs or {}).items():
+            k = {"K": "f", "steps": "epochs"}.get(k, k)
+            if k not in kw:
+                raise ValueError("unknown als_kwargs entry %r" % k)
+            kw[k] = v
+        self.config = kw
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("RecommenderALS needs a GPU: the HIP path has no CPU fallback")
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        self.n_users, self.n_items = n_users, n_items
+        self.X = self.Y = None
+        self.Utrain = self.Utest = None
+        self.engine = None
+        self.start_epoch = 0
+        self.trace, self.eval_epochs, self.eval_scores = [], [], []
+        if mode == "predict":
+            if model_path is None:
+                raise ValueError("mode='predict' needs model_path")
+            self.load(model_path)
+
+    # ------------------------------------------------------------------ data
+    def input_data(self, data):
+        """`data`: an object with make_training_datasets(dtype='sparse') -> (Utrain, Utest) and
+        N / M properties (the ExplicitData contract, reclibwh/utils/ItemMetadata.py:378-392), a
+        (Utrain, Utest) tuple of scipy sparse matrices, or one scipy sparse matrix [users, items]."""
+        import scipy.sparse as sps
+        if hasattr(data, "make_training_datasets"):
+            Utrain, Utest = data.make_training_datasets(dtype="sparse")
+        elif isinstance(data, (tuple, list)):
+            Utrain, Utest = data
+        else:
+            Utrain, Utest = data, None
+        Utrain = sps.csr_matrix(Utrain); Utrain.sort_indices()
+        if Utrain.nnz and Utrain.data.min() < 0:
+            raise ValueError("ratings must be >= 0 (implicit confidence c = 1 + alpha r)")
+        self.Utrain = Utrain
+        self.Utest = None if Utest is None else sps.csr_matrix(Utest)
+        if self.Utest is not None:
+            self.Utest.sort_indices()
+        N, M = Utrain.shape
+        if self.n_users is None: self.n_users = N
+        if self.n_items is None: self.n_items = M
+        if (self.n_users, self.n_items) != (N, M):
+            raise ValueError("data is %d x %d but the model was declared %d x %d" % (N, M, self.n_users, self.n_items))
+        if self.X is not None and (self.X.shape[0] < N or self.Y.shape[0] < M):
+            raise ValueError("loaded factors are smaller than the data")
+        return self
+
+    def _ensure_factors(self):
+        if self.X is not None:
+            return
+        c = self.config
+        ph = int(c["phantom_rows"])
+        X0, Y0 = init_factors(self.n_users + ph, self.n_items + ph, c["f"], c["init"], c["seed"])
+        self.X = torch.from_numpy(X0.astype(np.float32)).to(self.device)
+        self.Y = torch.from_numpy(Y0.astype(np.float32)).to(self.device)
+
+    def _ensure_engine(self):
+        if self.engine is not None:
+            return
+        if self.Utrain is None:
+            raise RuntimeError("call input_data() first")
+        self._ensure_factors()
+        import scipy.sparse as sps
+        c = self.config
+        Ut = sps.csr_matrix(self.Utrain.T); Ut.sort_indices()
+        cu = ops.DeviceCSR.from_scipy(self.Utrain, self.device, c["chunk_nnz"])
+        ci = ops.DeviceCSR.from_scipy(Ut, self.device, c["chunk_nnz"])
+        self.engine = ALSEngine(cu, ci, self.X, self.Y, c["lamb"], c["alpha"])
+
+    # ------------------------------------------------------------------ training
+    def train(self, epochs=None, evaluate=None):
+        """Runs the remaining epochs (ALSTrainer.fit, ALS.py:343-353).  evaluate: None = evaluate
+        after every epoch iff test data was given (the reference's EvalCallback), False = never."""
+        if self.mode != "train":
+            raise RuntimeError("cannot call train() when mode is not 'train'")        # ALS.py:124
+        self._ensure_engine()
+        epochs = self.config["epochs"] if epochs is None else int(epochs)
+        do_eval = (self.Utest is not None) if evaluate is None else bool(evaluate)
+        for epoch in range(self.start_epoch, epochs):
+            self.engine.step()
+            self.trace.append(self.engine.last_delta())
+            if do_eval:
+                self.eval_epochs.append(epoch); self.eval_scores.append(self.evaluate())
+            self.start_epoch = epoch + 1
+            if self.model_path is not None:
+                self.save(self.model_path)                                              # ALS.py:353
+        bad = int(self.engine.info.item())
+        if bad:
+            raise FloatingPointError("%d row systems were not positive definite in float32" % bad)
+        return self.trace
+
+    # ------------------------------------------------------------------ persistence
+    def save(self, path=None):
+        path = self.model_path if path is None else path
+        if path is None:
+            raise ValueError("model path not specified")                                # ALS.py:145
+        if self.X is None:
+            raise RuntimeError("nothing to save")
+        os.makedirs(path, exist_ok=True)
+        ph = int(self.config["phantom_rows"])
+        X = self.X.cpu().numpy().astype(np.float64); Y = self.Y.cpu().numpy().astype(np.float64)
+        if ph:
+            X, Y = X[:-ph], Y[:-ph]
+        np.save(os.path.join(path, "X.npy"), X)
+        np.save(os.path.join(path, "Y.npy"), Y)
+        c = self.config
+        cfg = {"epochs": c["epochs"], "start_epoch": self.start_epoch, "alpha": c["alpha"], "lamb": c["lamb"]}
+        with open(os.path.join(path, "algorithm_config.json"), "w") as fp:
+            json.dump(cfg, fp)
+        if self.eval_scores:
+            with open(os.path.join(path, "eval.csv"), "w") as fp:
+                fp.write("epoch,score\n")
+                for e, s in zip(self.eval_epochs, self.eval_scores):
+                    fp.write("%s,%s\n" % (float(e), repr(float(s))))
+        if self.trace:
+            with open(os.path.join(path, "trace.csv"), "w") as fp:
+                fp.write("trace\n" + "\n".join(repr(float(t)) for t in self.trace) + "\n")
+
+    def load(self, path):
+        X = np.load(os.path.join(path, "X.npy"), allow_pickle=False)                    # ALS.py:151-154
+        Y = np.load(os.path.join(path, "Y.npy"), allow_pickle=False)
+        if X.ndim != 2 or Y.ndim != 2 or X.shape[1] != Y.shape[1]:
+            raise ValueError("X.npy / Y.npy have inconsistent shapes")
+        self.config["f"] = int(X.shape[1])
+        self.config["phantom_rows"] = 0
+        self.n_users, self.n_items = X.shape[0], Y.shape[0]
+        self.X = torch.from_numpy(X.astype(np.float32)).to(self.device)
+        self.Y = torch.from_numpy(Y.astype(np.float32)).to(self.device)
+        cfgp = os.path.join(path, "algorithm_config.json")
+        if os.path.exists(cfgp):
+            with open(cfgp) as fp:
+                cfg = json.load(fp)
+            for k in ("epochs", "alpha", "lamb"):
+                if k in cfg: self.config[k] = cfg[k]
+            self.start_epoch = int(cfg.get("start_epoch", 0))
+        self.engine = None
+        return self
+
+    # ------------------------------------------------------------------ inference
+    def _idx(self, a):
+        return torch.as_tensor(np.asarray(a, dtype=np.int64).reshape(-1), device=self.device)
+
+    def predict(self, u_in, i_in):
+        """p[k] = <X[u_in[k]], Y[i_in[k]]> for paired index arrays (ALS.py:359-362)."""
+        return ops.predict_pairs(self.X, self.Y, self._idx(u_in), self._idx(i_in)).cpu().numpy()
+
+    def recommend(self, users, k=200, filter_rated=False):
+        """Ranked items and scores for `users`: (idx [nu, k], scores [nu, k]), best first
+        (SimpleMFRecAlgo.recommend, RecAlgos.py:20-32, truncated to the k the reference's consumers
+        read: 200).  filter_rated drops items the user rated in the training data
+        (RecommenderService.py:16-29)."""
+        k = min(int(k), self.n_items)
+        ex = (self.Utrain.indptr.astype(np.int64), self.Utrain.indices) if (filter_rated and self.Utrain is not None) else None
+        idx, val = ops.recommend_topk(self.X, self.Y, self._idx(users), k, M=self.n_items, exclude_csr=ex)
+        return idx.cpu().numpy().astype(np.int64), val.cpu().numpy()
+
+    def similar_to(self, items, k=200):
+        """Items most cosine-similar to each of `items` in item-factor space, best first (the item
+        itself comes first): SimpleMFSimAlgo.similar with output_emb='Y' (RecAlgos.py:61-73,
+        ALS.py:412)."""
+        k = min(int(k), self.n_items)
+        Yn = ops.normalize_rows(self.Y[: self.n_items])
+        idx, val = ops.recommend_topk(Yn, Yn, self._idx(items), k, M=self.n_items)
+        return idx.cpu().numpy().astype(np.int64), val.cpu().numpy()
+
+    def update_user(self, rows, cols, vals):
+        """Fold-in (ALSUpdateAlgo.make_update_data + update_user, ALS.py:375-395): re-solves the
+        factor rows of the users in `rows` from the given (row, col, val) triplets alone, against
+        the current item factors.  Unlike the reference the item Gram is refreshed first
+        (the reference reuses the cache of the last training epoch)."""
+        import scipy.sparse as sps
+        rows = np.asarray(rows, dtype=np.int64); cols = np.asarray(cols, dtype=np.int64)
+        vals = np.asarray(vals, dtype=np.float64)
+        if len(rows) == 0:
+            return
+        if rows.max() >= self.X.shape[0] or cols.max() >= self.n_items:
+            raise ValueError("row or column id outside the model")
+        uniq, inv = np.unique(rows, return_inverse=True)
+        U = sps.csr_matrix((vals, (inv, cols)), shape=(len(uniq), self.n_items))   # duplicates sum, as csr_matrix does
+        U.sort_indices()
+        csr = ops.DeviceCSR.from_scipy(U, self.device, self.config["chunk_nnz"], row_ids=uniq)
+        cache = ops.gram(self.Y, self.config["lamb"])
+        info = torch.zeros(1, dtype=torch.int32, device=self.device)
+        ops.half_sweep(csr, self.Y, cache, self.X, self.config["alpha"], info=info)
+        if int(info.item()):
+            raise FloatingPointError("fold-in system not positive definite in float32")
+
+    def evaluate(self, users=None):
+        """The reference's per-epoch score (AUCEval.evaluate, EvalProto.py:28-62): mean average
+        precision over the first 200 recommendations, test items rated above med_score relevant,
+        training items filtered.  Default users: those with < 50 training ratings, thinned to
+        ~300 (ALS.py:434-437)."""
+        if self.Utrain is None or self.Utest is None:
+            raise RuntimeError("evaluate() needs training and test data (input_data)")
+        users = metrics.users_to_test(self.Utrain) if users is None else np.asarray(users)
+        if len(users) == 0:
+            return float("nan")
+        lim = int(self.config["eval_lim"])
+        recs, _ = self.recommend(users, k=min(lim, self.n_items))
+        return metrics.mean_average_precision(recs, users, self.Utrain, self.Utest, self.config["med_score"], lim)

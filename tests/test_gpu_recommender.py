@@ -1,0 +1,176 @@
+"""GPU tests of the RecommenderALS facade and the scoring kernels against the oracle."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+torch = pytest.importorskip("torch")
+
+from oracle import als_ref, c_oracle  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ra():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import recommender_amd
+    return recommender_amd
+
+
+def _g2(golden):
+    g = golden("g2_powerlaw_train.npz")
+    shape = tuple(int(x) for x in g["U_shape"])
+    U = sps.csr_matrix((g["U_data"], g["U_indices"], g["U_indptr"]), shape=shape)
+    return g, U
+
+
+@pytest.mark.parametrize("K,conv", [(20, "ref"), (20, "tf"), (64, "ref"), (8, "tf")])
+def test_train_three_epochs_matches_alsref(ra, golden, K, conv):
+    """RecommenderALS.train() vs ALSRef.train() on identical CSR input and seed-42 init:
+    factors within 1e-4 relative (max-abs error / max-abs value) after every one of 3 epochs,
+    trace within 1e-4 relative.  Where the float32 build of the CPU oracle itself cannot hold
+    1e-4 against float64 (K=64 with only 200 users: the user Gram is close to singular), the
+    bound is 3x that float32 deviation instead."""
+    g, U = _g2(golden)
+    tag = "K%d_%s" % (K, conv)
+    Ut = sps.csr_matrix(U.T); Ut.sort_indices()
+    Xf, Yf = g[tag + "_X0"].astype(np.float32), g[tag + "_Y0"].astype(np.float32)
+    rec = ra.RecommenderALS(mode="train", n_users=U.shape[0], n_items=U.shape[1],
+                            als_kwargs={"K": K, "lamb": 0.01, "alpha": 40.0, "steps": 3, "init": conv})
+    rec.input_data(U)
+    for ep in range(1, 4):
+        rec.train(epochs=ep)
+        X = rec.X.cpu().numpy().astype(np.float64); Y = rec.Y.cpu().numpy().astype(np.float64)
+        Xg, Yg = g["%s_X%d" % (tag, ep)], g["%s_Y%d" % (tag, ep)]
+        Xf = c_oracle.half_sweep(U.indptr, U.indices, U.data, Yf, Xf, 0.01, 40.0, dtype=np.float32)
+        Yf = c_oracle.half_sweep(Ut.indptr, Ut.indices, Ut.data, Xf, Yf, 0.01, 40.0, dtype=np.float32)
+        ex = np.abs(X - Xg).max() / np.abs(Xg).max(); ey = np.abs(Y - Yg).max() / np.abs(Yg).max()
+        fx = np.abs(Xf - Xg).max() / np.abs(Xg).max(); fy = np.abs(Yf - Yg).max() / np.abs(Yg).max()
+        assert ex < max(1e-4, 3 * fx) and ey < max(1e-4, 3 * fy), (ep, ex, ey, fx, fy)
+    np.testing.assert_allclose(rec.trace, g[tag + "_trace"], rtol=2e-4)
+
+
+def test_save_load_predict_roundtrip(ra, golden, tmp_path):
+    g, U = _g2(golden)
+    path = str(tmp_path / "model")
+    rec = ra.RecommenderALS(mode="train", n_users=U.shape[0], n_items=U.shape[1],
+                            als_kwargs={"f": 20, "lamb": 0.01, "alpha": 40.0, "epochs": 2}, model_path=path)
+    rec.input_data(U); rec.train(); rec.save(path)
+    X = np.load(os.path.join(path, "X.npy")); Y = np.load(os.path.join(path, "Y.npy"))
+    assert X.dtype == np.float64 and X.shape == (U.shape[0], 20) and Y.shape == (U.shape[1], 20)
+    cfg = __import__("json").load(open(os.path.join(path, "algorithm_config.json")))
+    assert cfg == {"epochs": 2, "start_epoch": 2, "alpha": 40.0, "lamb": 0.01}
+    again = ra.RecommenderALS(mode="predict", model_path=path)
+    u = np.array([0, 5, 199, 7]); i = np.array([3, 149, 0, 7])
+    p = again.predict(u, i)
+    np.testing.assert_allclose(p, np.einsum("ij,ij->i", X[u], Y[i]), rtol=2e-5, atol=1e-6)
+    with pytest.raises(RuntimeError):
+        again.train()
+    # resuming: a model restored in train mode continues from start_epoch; the saved config
+    # (epochs included) replaces the constructor's, as ALSTrainer.__env_restore does (ALS.py:297-298)
+    cont = ra.RecommenderALS(mode="train", als_kwargs={"f": 20, "lamb": 0.5, "alpha": 1.0, "epochs": 9})
+    cont.load(path); cont.input_data(U)
+    assert cont.config["epochs"] == 2 and cont.config["lamb"] == 0.01 and cont.train() == []
+    cont.train(epochs=3)
+    assert cont.start_epoch == 3 and len(cont.trace) == 1
+    ref = np.abs(cont.X.cpu().numpy() - g["K20_ref_X3"]).max() / np.abs(g["K20_ref_X3"]).max()
+    assert ref < 1e-4
+
+
+def test_recommend_and_similar_match_reference_ranking(ra):
+    rng = np.random.default_rng(4)
+    N, M, f = 130, 777, 20
+    X = rng.normal(size=(N, f)); Y = rng.normal(size=(M, f)); Y[5] = 0.0      # a zero-norm item row
+    rec = ra.RecommenderALS(mode="train", n_users=N, n_items=M, als_kwargs={"f": f})
+    rec.X = torch.from_numpy(X.astype(np.float32)).cuda(); rec.Y = torch.from_numpy(Y.astype(np.float32)).cuda()
+    users = np.array([3, 0, 129, 64, 3])
+    idx, sc = rec.recommend(users, k=200)
+    ridx, rsc = als_ref.recommend_full(X.astype(np.float32).astype(np.float64), Y.astype(np.float32).astype(np.float64), users)
+    np.testing.assert_allclose(sc, rsc[:, :200], rtol=1e-5, atol=1e-5)
+    assert (idx == ridx[:, :200]).mean() > 0.999               # identical ranking up to float32 near-ties
+    assert np.all(np.diff(sc, axis=1) <= 0)
+    items = np.array([0, 5, 776])
+    sidx, ssc = rec.similar_to(items, k=50)
+    oidx, osc = als_ref.cosine_similar(Y.astype(np.float32).astype(np.float64), items)
+    np.testing.assert_allclose(ssc[[0, 2]], osc[[0, 2], :50], rtol=1e-5, atol=1e-5)
+    assert sidx[0, 0] == 0 and sidx[2, 0] == 776 and np.all(ssc[1] == 0)       # zero row: all similarities 0
+    assert (sidx[[0, 2]] == oidx[[0, 2], :50]).mean() > 0.99
+
+
+def test_topk_ties_exclusions_and_large_rows(ra):
+    rng = np.random.default_rng(8)
+    n, M = 7, 100003
+    S = rng.integers(0, 50, size=(n, M)).astype(np.float32)                    # massive ties
+    S[2, :] = -np.inf; S[2, 17] = 1.0; S[3, 5] = np.nan
+    ex_rows = [np.sort(rng.choice(M, size=c, replace=False)).astype(np.int32) for c in (0, 10, 3, 500, 0, 1, 99)]
+    ptr = np.zeros(n + 1, dtype=np.int64); np.cumsum([len(e) for e in ex_rows], out=ptr[1:])
+    for k in (1, 100, 1000):
+        Sd = torch.from_numpy(S.copy()).cuda()
+        idx, val = ra.topk_rows(Sd, k, (torch.from_numpy(ptr).cuda(), torch.from_numpy(np.concatenate(ex_rows)).cuda()))
+        idx = idx.cpu().numpy(); val = val.cpu().numpy()
+        for r in range(n):
+            row = S[r].copy(); row[ex_rows[r]] = -np.inf
+            row = np.where(np.isnan(row), -np.inf, row)                        # NaN ranks below everything
+            order = np.lexsort((np.arange(M), -row))[:k]                      # score desc, id asc
+            assert np.array_equal(idx[r], order), (k, r)
+            exp = row[order]
+            assert np.array_equal(val[r][np.isfinite(exp)], exp[np.isfinite(exp)])
+
+
+def test_scores_edge_shapes(ra):
+    rng = np.random.default_rng(2)
+    for (nu, M, f) in [(1, 1, 5), (65, 257, 20), (3, 1000, 64), (70, 300, 50)]:
+        X = rng.normal(size=(nu, f)).astype(np.float32); Y = rng.normal(size=(M, f)).astype(np.float32)
+        S = ra.scores(torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda()).cpu().numpy()
+        np.testing.assert_allclose(S, X.astype(np.float64) @ Y.astype(np.float64).T, rtol=1e-5, atol=1e-5)
+
+
+def test_update_user_foldin(ra, golden):
+    """test_ALS.py:88-101: a new user given user 0's ratings gets user 0's factors."""
+    g, U = _g2(golden)
+    N, M = U.shape
+    rec = ra.RecommenderALS(mode="train", n_users=N, n_items=M,
+                            als_kwargs={"f": 20, "lamb": 0.01, "alpha": 40.0, "epochs": 2, "phantom_rows": 1})
+    rec.input_data(U); rec.train()
+    r, c, v = sps.find(U[0])
+    rows = np.concatenate([r, np.full_like(r, N)])          # the phantom row N plays the brand-new user
+    before = rec.X.clone()
+    rec.update_user(rows, np.concatenate([c, c]), np.concatenate([v, v]))
+    X = rec.X.cpu().numpy()
+    assert np.array_equal(X[0], X[N])
+    assert torch.equal(rec.X[1:N], before[1:N])
+    # and it equals the oracle's fold-in of that row against the current item factors
+    Yc = rec.Y.cpu().numpy().astype(np.float64)
+    one = sps.csr_matrix(U[0])
+    ref = als_ref.half_sweep_exact(one.indptr, one.indices, one.data, Yc, np.zeros((1, 20)), 0.01, 40.0)
+    assert np.abs(X[0] - ref[0]).max() / np.abs(ref[0]).max() < 1e-4
+
+
+def test_evaluate_matches_oracle_map(ra):
+    """MAP@200 on a block-structured matrix (ExplicitDataDummy-like): same value as the oracle's
+    evaluation of the oracle's factors to 3 decimals, and > 0.9 as tests/core/test_ALS.py:85-86."""
+    rng = np.random.default_rng(12)
+    m, n, nb = 10, 20, 10
+    rows, cols, data = [], [], []
+    for b in range(nb):
+        rr, cc = np.meshgrid(np.arange(n * b, n * (b + 1)), np.arange(m * b, m * (b + 1)), indexing="ij")
+        rows.append(rr.ravel()); cols.append(cc.ravel()); data.append(np.full(rr.size, b % 5 + 1.0))
+    rows, cols, data = map(np.concatenate, (rows, cols, data))
+    perm = rng.permutation(len(data)); cut = int(0.8 * len(data))
+    N, M = n * nb, m * nb
+    tr = sps.csr_matrix((data[perm[:cut]], (rows[perm[:cut]], cols[perm[:cut]])), shape=(N, M))
+    te = sps.csr_matrix((data[perm[cut:]], (rows[perm[cut:]], cols[perm[cut:]])), shape=(N, M))
+    tr.sort_indices(); te.sort_indices()
+    rec = ra.RecommenderALS(mode="train", n_users=N, n_items=M, als_kwargs={"f": 20, "lamb": 1e-2, "alpha": 40.0, "epochs": 3})
+    rec.input_data((tr, te)); rec.train()
+    users = np.arange(N)
+    score = rec.evaluate(users)
+    X0, Y0 = als_ref.init_factors(N, M, 20, "ref")
+    Xo, Yo, _, _ = als_ref.train_exact(tr.indptr, tr.indices, tr.data, (N, M), 20, 1e-2, 40.0, 3, X0, Y0)
+    oidx, _ = als_ref.recommend_full(Xo, Yo, users)
+    oscore = als_ref.map_at_k(oidx, (te.indptr, te.indices, te.data), (tr.indptr, tr.indices, tr.data), users, 3.0, 200)
+    assert abs(score - oscore) < 5e-4 and score > 0.9, (score, oscore)
+    assert len(rec.eval_scores) == 3

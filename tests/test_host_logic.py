@@ -1,0 +1,103 @@
+"""CPU-only tests: host logic, the C-ABI library's exported symbols, metrics and init against
+the golden vectors.  No compute call is made here (there is no GPU in this environment)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "als_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(als_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 14
+    lib = ctypes.CDLL(os.path.join(ROOT, "recommender_amd", "libals_hip.so"))
+    for n in sorted(names):
+        assert hasattr(lib, n), "libals_hip.so does not export %s" % n
+    from recommender_amd import _lib
+    assert names == set(_lib.SIGNATURES), names ^ set(_lib.SIGNATURES)
+    assert _lib.lib.als_abi_version() >= 1
+
+
+def test_error_strings_and_argument_checks_without_gpu():
+    from recommender_amd._lib import lib
+    n = ctypes.c_int64()
+    ptr = np.array([0, 3, 1], dtype=np.int64)       # decreasing row pointer
+    rc = lib.als_plan_count(ptr.ctypes.data, 2, 2048, ctypes.byref(n), ctypes.byref(n), ctypes.byref(n))
+    assert rc == 1 and b"non-decreasing" in lib.als_last_error_string()
+    rc = lib.als_plan_count(ptr.ctypes.data, 2, 100, ctypes.byref(n), ctypes.byref(n), ctypes.byref(n))
+    assert rc == 1 and b"multiple of 64" in lib.als_last_error_string()
+    assert lib.als_gram_tiles_bytes(0) == 0 and lib.als_gram_tiles_bytes(64) == 40 * 64 * 4
+    assert lib.als_half_sweep_workspace_bytes(10, 0, 1000) == 0
+
+
+@pytest.mark.parametrize("chunk", [64, 2048])
+def test_plan_covers_every_row_once(chunk):
+    from recommender_amd import build_plan
+    rng = np.random.default_rng(3)
+    lens = np.concatenate([rng.integers(0, 300, size=500), [0, 0, 5000, 64, 65, chunk, chunk + 1, 3 * chunk]])
+    ptr = np.zeros(len(lens) + 1, dtype=np.int64); np.cumsum(lens, out=ptr[1:])
+    items, long_rows, n_slots = build_plan(ptr, chunk)
+    direct = items[items[:, 1] < 0]
+    chunks = items[items[:, 1] >= 0]
+    assert sorted(direct[:, 0].tolist() + long_rows[:, 0].tolist()) == list(range(len(lens)))
+    assert np.all(lens[direct[:, 0]] <= chunk) and np.all(lens[long_rows[:, 0]] > chunk)
+    assert np.all(np.diff(lens[direct[:, 0]]) <= 0)                      # longest first
+    assert n_slots == len(chunks) and sorted(chunks[:, 2].tolist()) == list(range(n_slots))
+    for r, first, n, _ in long_rows:
+        assert n == -(-lens[r] // chunk)
+        mine = chunks[chunks[:, 0] == r]
+        assert mine[:, 1].tolist() == list(range(n)) and mine[:, 2].tolist() == list(range(first, first + n))
+    assert len(items) == len(direct) + n_slots
+
+
+def test_init_factors_match_reference_streams(golden):
+    from recommender_amd.als import init_factors
+    g = golden("g2_powerlaw_train.npz")
+    N, M = (int(x) for x in g["U_shape"])
+    for K in (8, 20, 64):
+        for conv in ("ref", "tf"):
+            X0, Y0 = init_factors(N, M, K, conv)
+            assert np.array_equal(X0, g["K%d_%s_X0" % (K, conv)]) and np.array_equal(Y0, g["K%d_%s_Y0" % (K, conv)])
+
+
+def test_metrics_match_reference(golden):
+    from recommender_amd import metrics
+    g = golden("g4_metrics.npz")
+    for k in range(g["rec"].shape[0]):
+        rec = g["rec"][k][g["rec"][k] >= 0]; te = g["test"][k][g["test"][k] >= 0]; tr = g["train"][k][g["train"][k] >= 0]
+        assert metrics.compute_ap(rec, te, tr) == pytest.approx(g["ap"][k], abs=1e-15)
+        assert metrics.compute_auc(rec, te, tr) == pytest.approx(g["auc"][k], abs=1e-15)
+    assert metrics.rmse(g["rmse_x"], g["rmse_y"]) == pytest.approx(float(g["rmse"]), abs=1e-15)
+
+
+def test_balanced_ranges():
+    from recommender_amd.als import balanced_ranges
+    rng = np.random.default_rng(0)
+    lens = rng.zipf(1.5, size=10000).clip(max=5000)
+    ptr = np.zeros(len(lens) + 1, dtype=np.int64); np.cumsum(lens, out=ptr[1:])
+    for parts in (1, 2, 3, 8):
+        b = balanced_ranges(ptr, parts)
+        assert b[0] == 0 and b[-1] == len(lens) and np.all(np.diff(b) >= 0) and len(b) == parts + 1
+        share = np.diff(ptr[b])
+        assert share.max() <= ptr[-1] / parts + lens.max()
+    assert balanced_ranges(np.zeros(11, dtype=np.int64), 2).tolist() == [0, 5, 10]
+
+
+def test_synthetic_generator_is_canonical_and_seeded():
+    import torch
+    from recommender_amd import data
+    U, Ut = data.synth_matrix(300, 200, 5000, seed=11, device="cpu")
+    U2, _ = data.synth_matrix(300, 200, 5000, seed=11, device="cpu")
+    assert all(torch.equal(a, b) for a, b in zip(U, U2))
+    ptr, col, val = (t.numpy() for t in U)
+    assert ptr[-1] == 5000 == len(col) and val.min() >= 0.5 and val.max() <= 5.0
+    for r in range(300):
+        c = col[ptr[r]:ptr[r + 1]]
+        assert np.all(np.diff(c) > 0)                                      # sorted, duplicate free
+    A = data.to_scipy(U, (300, 200)); At = data.to_scipy(Ut, (200, 300))
+    assert (A.T != At).nnz == 0
