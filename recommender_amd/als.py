@@ -52,34 +52,35 @@ def balanced_ranges(rowptr, parts):
 
 
 # ----------------------------------------------------------------------------- operators
-def als_update_cache(Y, lamb, cache=None, group=None):
+def als_update_cache(Y, lamb, cache=None, group=None, backend=ops):
     """Y2 <- Y^T Y over all rows of Y (pad/phantom rows included), LambdaI <- lamb I
     (ALS.py:235-246).  With a process group, each rank reduces its share of the fixed
-    65 536-row partials and the partials are all-gathered and summed in row order."""
+    65 536-row partials and the partials are all-gathered and summed in row order.
+    `backend` supplies gram / gram_partials / gram_finalize (default: the HIP operators)."""
     world = torch.distributed.get_world_size(group) if group is not None else 1
     n, f = Y.shape
     n_super = -(-n // _lib.GRAM_SUPER_ROWS)
     if world == 1 or n_super < 2 * world:
-        return ops.gram(Y, lamb, out=cache)
+        return backend.gram(Y, lamb, out=cache)
     rank = torch.distributed.get_rank(group)
     cuts = [(n_super * r) // world for r in range(world + 1)]
     s0, s1 = cuts[rank], cuts[rank + 1]
-    mine = ops.gram_partials(Y, s0 * _lib.GRAM_SUPER_ROWS, min(n, s1 * _lib.GRAM_SUPER_ROWS))
+    mine = backend.gram_partials(Y, s0 * _lib.GRAM_SUPER_ROWS, min(n, s1 * _lib.GRAM_SUPER_ROWS))
     cnt_max = max(cuts[r + 1] - cuts[r] for r in range(world))
     elems = mine.shape[1]
-    send = torch.zeros((cnt_max, elems), dtype=torch.float32, device=Y.device)
+    send = torch.zeros((cnt_max, elems), dtype=mine.dtype, device=Y.device)
     send[: mine.shape[0]] = mine
-    recv = torch.empty((world * cnt_max, elems), dtype=torch.float32, device=Y.device)
+    recv = torch.empty((world * cnt_max, elems), dtype=mine.dtype, device=Y.device)
     torch.distributed.all_gather_into_tensor(recv, send, group=group)
     parts = [recv[r * cnt_max: r * cnt_max + (cuts[r + 1] - cuts[r])] for r in range(world)]
-    return ops.gram_finalize(torch.cat(parts, 0).contiguous(), f, lamb, out=cache)
+    return backend.gram_finalize(torch.cat(parts, 0).contiguous(), f, lamb, out=cache)
 
 
-def run_als_epoch(csr, X, Y, cache, alpha, absdiff=None, info=None):
+def run_als_epoch(csr, X, Y, cache, alpha, absdiff=None, info=None, backend=ops):
     """One half-sweep over the rows of `csr`: re-solves those rows of X in place against the
     fixed Y and its cache (ALS.py:201-233).  Returns the device scalar sum|X_old - X_new|
     (float64); the reference's return value is that divided by n_rows * f."""
-    return ops.half_sweep(csr, Y, cache, X, alpha, absdiff=absdiff, info=info)
+    return backend.half_sweep(csr, Y, cache, X, alpha, absdiff=absdiff, info=info)
 
 
 def _all_gather_rows(T, bounds, rank, group):
@@ -105,8 +106,10 @@ class ALSEngine:
     replicas.  Single GPU: bounds = [0, n].
     """
 
-    def __init__(self, csr_users, csr_items, X, Y, lamb, alpha, user_bounds=None, item_bounds=None, group=None):
+    def __init__(self, csr_users, csr_items, X, Y, lamb, alpha, user_bounds=None, item_bounds=None, group=None,
+                 backend=ops):
         self.group = group
+        self.backend = backend      # the HIP operators; tests inject a CPU stand-in to exercise the sharding logic
         self.world = torch.distributed.get_world_size(group) if group is not None else 1
         self.rank = torch.distributed.get_rank(group) if group is not None else 0
         self.csr_users, self.csr_items = csr_users, csr_items
@@ -124,8 +127,8 @@ class ALSEngine:
         self.n_users, self.n_items = self.user_bounds[-1], self.item_bounds[-1]
         if X.shape[0] < self.n_users or Y.shape[0] < self.n_items:
             raise ValueError("factor matrices are smaller than the rating matrix")
-        self.cache_Y = ops.GramCache(self.f, lamb, X.device)
-        self.cache_X = ops.GramCache(self.f, lamb, X.device)
+        self.cache_Y = backend.GramCache(self.f, lamb, X.device)
+        self.cache_X = backend.GramCache(self.f, lamb, X.device)
         self._dX = torch.zeros(1, dtype=torch.float64, device=X.device)
         self._dY = torch.zeros(1, dtype=torch.float64, device=X.device)
         self.info = torch.zeros(1, dtype=torch.int32, device=X.device)
@@ -136,16 +139,18 @@ class ALSEngine:
     def step(self):
         u0, u1 = self.user_bounds[self.rank], self.user_bounds[self.rank + 1]
         i0, i1 = self.item_bounds[self.rank], self.item_bounds[self.rank + 1]
-        als_update_cache(self.Y, self.lamb, self.cache_Y, self.group)
+        als_update_cache(self.Y, self.lamb, self.cache_Y, self.group, self.backend)
         if u1 > u0:
             if self.pre_sweep_hook: self.pre_sweep_hook("users")
-            run_als_epoch(self.csr_users, self.X[u0:u1], self.Y, self.cache_Y, self.alpha, self._dX, self.info)
+            run_als_epoch(self.csr_users, self.X[u0:u1], self.Y, self.cache_Y, self.alpha, self._dX, self.info,
+                          self.backend)
         if self.world > 1:
             _all_gather_rows(self.X[: self.n_users], self.user_bounds, self.rank, self.group)
-        als_update_cache(self.X, self.lamb, self.cache_X, self.group)
+        als_update_cache(self.X, self.lamb, self.cache_X, self.group, self.backend)
         if i1 > i0:
             if self.pre_sweep_hook: self.pre_sweep_hook("items")
-            run_als_epoch(self.csr_items, self.Y[i0:i1], self.X, self.cache_X, self.alpha, self._dY, self.info)
+            run_als_epoch(self.csr_items, self.Y[i0:i1], self.X, self.cache_X, self.alpha, self._dY, self.info,
+                          self.backend)
         if self.world > 1:
             _all_gather_rows(self.Y[: self.n_items], self.item_bounds, self.rank, self.group)
 

@@ -1,0 +1,84 @@
+"""world_size > 1 on CPU (gloo): the engine's sharded run must reproduce the single-process run
+bit for bit - equal row shards (all_gather_into_tensor path), unequal shards (broadcast path),
+sharded Gram (fixed 65 536-row partials all-gathered and summed in row order) and the replicated
+Gram of a small factor.  The HIP operators are replaced by tests/oracle_backend.py."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _problem(N, M, f, seed):
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(0, 4, size=N).astype(np.int64)
+    lens[:50] = rng.integers(20, 60, size=50)                     # a few heavy users: unequal nnz-balanced shards
+    ptr = np.zeros(N + 1, dtype=np.int64); np.cumsum(lens, out=ptr[1:])
+    ind = rng.integers(0, M, size=ptr[-1]).astype(np.int32)
+    for u in range(N):                                            # canonical rows
+        s, e = ptr[u], ptr[u + 1]
+        c = np.unique(ind[s:e])
+        lens[u] = len(c); ind[s:s + len(c)] = c
+    ptr2 = np.zeros(N + 1, dtype=np.int64); np.cumsum(lens, out=ptr2[1:])
+    ind = np.concatenate([ind[ptr[u]:ptr[u] + lens[u]] for u in range(N)]).astype(np.int32)
+    dat = rng.integers(1, 11, size=ptr2[-1]) * 0.5
+    X0 = rng.normal(0, 0.5, size=(N, f)); Y0 = rng.normal(0, 0.5, size=(M, f))
+    return ptr2, ind, dat, X0, Y0
+
+
+def _run(rank, world, port, N, M, f, balance, out_dir):
+    import oracle_backend as ob
+    from oracle import als_ref
+    from recommender_amd.als import ALSEngine, balanced_ranges
+    group = None
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+        group = torch.distributed.group.WORLD
+    ptr, ind, dat, X0, Y0 = _problem(N, M, f, 5)
+    tptr, tind, tdat = als_ref.csr_transpose(ptr, ind, dat, M)
+    if balance == "nnz":
+        ub = balanced_ranges(ptr, world); ib = balanced_ranges(tptr, world)
+    else:
+        ub = np.linspace(0, N, world + 1).astype(np.int64); ib = np.linspace(0, M, world + 1).astype(np.int64)
+
+    def shard(p, i, d, b0, b1, ncols):
+        return ob.HostCSR(p[b0:b1 + 1] - p[b0], i[p[b0]:p[b1]], d[p[b0]:p[b1]], (b1 - b0, ncols))
+
+    cu = shard(ptr, ind, dat, ub[rank], ub[rank + 1], M)
+    ci = shard(tptr, tind, tdat, ib[rank], ib[rank + 1], N)
+    X = torch.from_numpy(X0.copy()); Y = torch.from_numpy(Y0.copy())
+    eng = ALSEngine(cu, ci, X, Y, 0.05, 3.0, ub, ib, group, backend=ob)
+    trace = eng.fit(2)
+    np.savez(os.path.join(out_dir, "w%d_r%d_%s.npz" % (world, rank, balance)), X=X.numpy(), Y=Y.numpy(), trace=trace)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,balance", [(2, "rows"), (2, "nnz"), (3, "nnz")])
+def test_sharded_run_equals_single_process(tmp_path, world, balance):
+    # 6 x 65 536 + 1000 users: 7 Gram super-partials -> the sharded Gram path for world 2 and 3;
+    # 300 items: the replicated Gram path.  N is divisible by 2 so that "rows" shards are equal.
+    N, M, f = 6 * 65536 + 1000, 300, 4
+    out = str(tmp_path)
+    _run(0, 1, 0, N, M, f, balance, out)
+    mp.spawn(_run, args=(world, _free_port(), N, M, f, balance, out), nprocs=world, join=True)
+    ref = np.load(os.path.join(out, "w1_r0_%s.npz" % balance))
+    assert np.all(np.isfinite(ref["X"])) and ref["trace"][1] < ref["trace"][0]
+    for r in range(world):
+        got = np.load(os.path.join(out, "w%d_r%d_%s.npz" % (world, r, balance)))
+        assert np.array_equal(got["X"], ref["X"]) and np.array_equal(got["Y"], ref["Y"])   # bit for bit, every rank
+        np.testing.assert_allclose(got["trace"], ref["trace"], rtol=1e-12)
