@@ -41,3 +41,25 @@ for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
             continue
         print("  " + k + "  " + "  ".join("%s=%.4g" % (c, sum(v) / len(v)) for c, v in sorted(agg[k].items())) +
               "  (n=%d)" % len(next(iter(agg[k].values()))))
+
+# HBM traffic of the dominant kernel per launch, for bench.py's roofline.traffic.  FETCH_SIZE and
+# WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes for 16-byte-per-lane
+# loads (the sweep's gathers), so the read side is doubled; WRITE_SIZE is exact.
+import json
+fetch = write = None
+for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
+    cc = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True) if os.path.isdir(d) else []
+    for f in cc:
+        vals = collections.defaultdict(list)
+        for row in csv.DictReader(open(f)):
+            if "sweep_items_kernel" in row["Kernel_Name"]:
+                vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
+        if "FETCH_SIZE" in vals: fetch = sum(vals["FETCH_SIZE"]) / len(vals["FETCH_SIZE"])
+        if "WRITE_SIZE" in vals: write = sum(vals["WRITE_SIZE"]) / len(vals["WRITE_SIZE"])
+if fetch is not None and write is not None:
+    t = {"kernel": "sweep_items_kernel", "FETCH_SIZE_KiB_avg": fetch, "WRITE_SIZE_KiB_avg": write,
+         "hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024,
+         "note": "average over the user-sweep and item-sweep launches; read side = FETCH_SIZE x 2 (gfx950 correction)"}
+    json.dump(t, open(os.path.join(out, "pmc_traffic_entry.json"), "w"), indent=1)
+    print("== HBM traffic per sweep launch: %.3f GB (fetch x2 %.3f GB + write %.3f GB)" %
+          (t["hbm_bytes_per_launch"] / 1e9, fetch * 2048 / 1e9, write * 1024 / 1e9))
