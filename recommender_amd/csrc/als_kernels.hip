@@ -355,6 +355,179 @@ __device__ __forceinline__ float solve_row(const f32x4 (&acc)[Geo<VW>::NT], cons
     return d;
 }
 
+// ----------------------------------------------------------------------------- blocked solve
+// Solve in the accumulator layout, without LDS and without moving the matrix.
+//
+// The symmetric matrix sits in the wave as VW*(VW+1)/2 tiles of 16 x 16 (tile (ta, tb), ta <= tb):
+// lane (g, c) = (lane>>4, lane&15), register r holds element (row 4g+r, column c).  In the index
+// order p = 16*t + i (a permutation of the factor indices, harmless for an SPD system) this is a
+// VW x VW grid of contiguous blocks, so a right-looking block Cholesky A = U^T U applies:
+//   for kb:  X    = U_kk^{-1}                      (16 steps of elimination on the diagonal tile)
+//            U_kj = X^T A_kj        (jb > kb)       4 MFMAs per tile
+//            A_ij -= U_ki^T U_kj    (kb < ib <= jb) 4 MFMAs per tile
+// A product X^T Z of two tiles needs no data movement: register r of X and of Z are exactly the A
+// and B operands of v_mfma_f32_16x16x4_f32 for the 4 rows {4g+r}; the 4 registers cover all rows.
+// Vectors are kept "column indexed" (element c of a block in lane c, replicated over the 4 lane
+// groups) or "row indexed" (element 4g+r in register r of lane group g).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(const float x) {
+    // bound_ctrl = true: no lane is out of bounds for the controls used here, and it spares the
+    // compiler a zero-initialisation of the destination before every v_mov_b32_dpp
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+// sum over the 16 lanes of a row, result in every lane of the row (fixed butterfly order)
+__device__ __forceinline__ float row_sum16(float x) {
+    x += dpp_f<0xB1>(x);   // quad_perm [1,0,3,2]
+    x += dpp_f<0x4E>(x);   // quad_perm [2,3,0,1]
+    x += dpp_f<0x141>(x);  // row_half_mirror
+    x += dpp_f<0x140>(x);  // row_mirror
+    return x;
+}
+// sum over the 4 lane groups, result in every group
+__device__ __forceinline__ float grp_sum4(float x) {
+    x += __shfl_xor(x, 16);
+    x += __shfl_xor(x, 32);
+    return x;
+}
+// out (+)= X^T Z  (NEG: out -= X^T Z)
+template <bool NEG>
+__device__ __forceinline__ void tile_xtz(const f32x4 &X, const f32x4 &Z, f32x4 &out) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out = __builtin_amdgcn_mfma_f32_16x16x4f32(NEG ? -X[r] : X[r], Z[r], out, 0, 0, 0);
+}
+// column indexed -> row indexed
+__device__ __forceinline__ f32x4 vec_col_to_row(const float vcol, const int lane) {
+    const int g = lane >> 4;
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = __shfl(vcol, 20 * g + r);   // lane 16g + (4g + r)
+    return o;
+}
+// row indexed -> column indexed
+__device__ __forceinline__ float vec_row_to_col(const f32x4 &vrow, const int lane) {
+    const int c = lane & 15;
+    const float lo = (c & 1) ? vrow[1] : vrow[0], hi = (c & 1) ? vrow[3] : vrow[2];
+    const float tmp = (c & 2) ? hi : lo;
+    return __shfl(tmp, 16 * (c >> 2) + c);
+}
+// out[c] = sum_k X[k][c] v[k], v row indexed, out column indexed
+__device__ __forceinline__ float tile_xt_v(const f32x4 &X, const f32x4 &vrow) {
+    float p = X[0] * vrow[0];
+#pragma unroll
+    for (int r = 1; r < 4; ++r) p = fmaf(X[r], vrow[r], p);
+    return grp_sum4(p);
+}
+// out[k] = sum_c X[k][c] v[c], v column indexed, out row indexed
+__device__ __forceinline__ f32x4 tile_x_v(const f32x4 &X, const float vcol) {
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = row_sum16(X[r] * vcol);
+    return o;
+}
+
+// One elimination step on a diagonal tile D (pivot K) and on N, which accumulates the inverse of
+// the unit upper factor by the mirrored column operations.
+template <int K>
+__device__ __forceinline__ void diag_step(f32x4 &D, f32x4 &N, const int c) {
+    constexpr int reg = K & 3, src = 16 * (K >> 2);
+    const float d = readlane_f(D[reg], src + K);
+    float rd = __builtin_amdgcn_rcpf(d);
+    rd = rd * fmaf(-d, rd, 2.0f);                        // one Newton step on the reciprocal
+    const float rowk = __shfl(D[reg], src + c);          // row K of D in every lane group
+    const float nv = (c > K) ? -(rowk * rd) : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        D[r] = fmaf(dpp_f<0x150 + K>(D[r]), nv, D[r]);   // row_newbcast:K = D[4g+r][K]
+        N[r] = fmaf(dpp_f<0x150 + K>(N[r]), nv, N[r]);
+    }
+}
+template <int... Ks>
+__device__ __forceinline__ void diag_steps(f32x4 &D, f32x4 &N, const int c, std::integer_sequence<int, Ks...>) {
+    (diag_step<Ks>(D, N, c), ...);
+}
+// X = U_d^{-1} for the SPD tile D (U_d its upper Cholesky factor); ok = all pivots positive.
+__device__ __forceinline__ f32x4 diag_inverse_factor(f32x4 D, const int lane, bool &ok) {
+    const int g = lane >> 4, c = lane & 15;
+    f32x4 N;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) N[r] = (4 * g + r == c) ? 1.f : 0.f;
+    diag_steps(D, N, c, std::make_integer_sequence<int, 16>{});
+    // pivot d_c is still at lane (c>>2, c), register c&3 (column c is never touched after step c)
+    const float lo = (c & 1) ? D[1] : D[0], hi = (c & 1) ? D[3] : D[2];
+    const float dvec = __shfl((c & 2) ? hi : lo, 16 * (c >> 2) + c);
+    ok = ok && !__any(!(dvec > 0.f));
+    float sc = __builtin_amdgcn_rsqf(dvec);
+    sc = sc * fmaf(-0.5f * dvec * sc, sc, 1.5f);         // one Newton step on 1/sqrt(d)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) N[r] *= sc;
+    return N;
+}
+
+// Solves T x = b.  T: the VW*(VW+1)/2 tiles (destroyed), b: column-indexed right-hand side per
+// block (destroyed).  x: column-indexed solution per block.  Returns false if a pivot was <= 0.
+template <int VW>
+__device__ __forceinline__ bool blocked_solve(f32x4 (&T)[Geo<VW>::NT], float (&b)[VW], float (&x)[VW], const int lane) {
+    f32x4 Xd[VW], zrow[VW];
+    bool ok = true;
+#pragma unroll
+    for (int kb = 0; kb < VW; ++kb) {
+        const f32x4 X = diag_inverse_factor(T[tile_index(kb, kb, VW)], lane, ok);
+        Xd[kb] = X;
+#pragma unroll
+        for (int jb = kb + 1; jb < VW; ++jb) {
+            f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f};
+            tile_xtz<false>(X, T[tile_index(kb, jb, VW)], u);
+            T[tile_index(kb, jb, VW)] = u;
+        }
+        const float z = tile_xt_v(X, vec_col_to_row(b[kb], lane));     // z_kb = U_d^{-T} b_kb
+        zrow[kb] = vec_col_to_row(z, lane);
+#pragma unroll
+        for (int ib = kb + 1; ib < VW; ++ib) {
+            const f32x4 Ui = T[tile_index(kb, ib, VW)];
+#pragma unroll
+            for (int jb = ib; jb < VW; ++jb) tile_xtz<true>(Ui, T[tile_index(kb, jb, VW)], T[tile_index(ib, jb, VW)]);
+            b[ib] -= tile_xt_v(Ui, zrow[kb]);
+        }
+    }
+#pragma unroll
+    for (int kb = VW - 1; kb >= 0; --kb) {
+        f32x4 acc = zrow[kb];
+#pragma unroll
+        for (int jb = kb + 1; jb < VW; ++jb) acc -= tile_x_v(T[tile_index(kb, jb, VW)], x[jb]);
+        x[kb] = vec_row_to_col(tile_x_v(Xd[kb], vec_row_to_col(acc, lane)), lane);
+    }
+    return ok;
+}
+
+// (acc + gram_tiles) x = b for one row; writes x to xrow and returns sum |x_old - x_new| (all lanes).
+template <int VW>
+__device__ __forceinline__ float solve_row_blocked(f32x4 (&acc)[Geo<VW>::NT], float (&bacc)[VW],
+                                                   const float *__restrict__ gtiles, const int f,
+                                                   float *__restrict__ xrow, int32_t *info, const int lane) {
+#pragma unroll
+    for (int t = 0; t < Geo<VW>::NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] += gtiles[(t * 4 + r) * 64 + lane];
+    float x[VW];
+    const bool ok = blocked_solve<VW>(acc, bacc, x, lane);
+    const int j = lane & 15;
+    float d = 0.f;
+    if (lane < 16) {
+#pragma unroll
+        for (int t = 0; t < VW; ++t) {
+            const int idx = fidx<VW>(j, t);
+            if (idx < f) {
+                d += fabsf(xrow[idx] - x[t]);
+                xrow[idx] = x[t];
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) d += __shfl_xor(d, o);
+    if (!ok && lane == 0 && info) atomicAdd(info, 1);
+    return d;
+}
+
 // ----------------------------------------------------------------------------- kernels
 struct SweepParams {
     const int64_t *rowptr;
@@ -377,7 +550,9 @@ struct SweepParams {
 template <int VW, bool VEC, bool FULL>
 __global__ __launch_bounds__(64, ALS_SWEEP_WAVES) void sweep_items_kernel(const SweepParams p) {
     using G = Geo<VW>;
+#ifdef ALS_SOLVE_LANEROW
     __shared__ __attribute__((aligned(16))) float lds[G::TRI + G::FPAD + 128 + G::FPAD];
+#endif
     const int lane = threadIdx.x;
     const als_item_t it = p.items[blockIdx.x];
     const int row = it.row;
@@ -421,7 +596,11 @@ __global__ __launch_bounds__(64, ALS_SWEEP_WAVES) void sweep_items_kernel(const 
     } else {
 #else
     if (e > s) {
+#ifdef ALS_SOLVE_LANEROW
         d = solve_row<VW>(acc, bacc, p.gtiles, lds, p.f, xrow, p.info, lane);
+#else
+        d = solve_row_blocked<VW>(acc, bacc, p.gtiles, p.f, xrow, p.info, lane);
+#endif
     } else {
 #endif  // no entries: b = 0, so x = 0 exactly
         d = 0.f;
@@ -438,7 +617,9 @@ __global__ __launch_bounds__(64, ALS_SWEEP_WAVES) void sweep_items_kernel(const 
 template <int VW>
 __global__ __launch_bounds__(64) void sweep_long_rows_kernel(const SweepParams p) {
     using G = Geo<VW>;
+#ifdef ALS_SOLVE_LANEROW
     __shared__ __attribute__((aligned(16))) float lds[G::TRI + G::FPAD + 128 + G::FPAD];
+#endif
     const int lane = threadIdx.x;
     const als_long_row_t lr = p.long_rows[blockIdx.x];
     f32x4 acc[G::NT];
@@ -461,7 +642,11 @@ __global__ __launch_bounds__(64) void sweep_long_rows_kernel(const SweepParams p
     }
     const int row = lr.row;
     const int64_t xr = p.row_ids ? p.row_ids[row] : (int64_t)row;
+#ifdef ALS_SOLVE_LANEROW
     const float d = solve_row<VW>(acc, bacc, p.gtiles, lds, p.f, p.X + xr * p.ldx, p.info, lane);
+#else
+    const float d = solve_row_blocked<VW>(acc, bacc, p.gtiles, p.f, p.X + xr * p.ldx, p.info, lane);
+#endif
     if (lane == 0) p.rowdiff[row] = d;
 }
 
