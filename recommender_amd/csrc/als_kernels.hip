@@ -73,16 +73,23 @@ __host__ __device__ __forceinline__ constexpr int fidx(int j, int t) {
     else return (t < 4) ? 4 * j + t : 64 + 4 * j + (t - 4);
 }
 
-constexpr int GS = 4;  // k-steps per pipeline stage (16 gathered rows)
+// k-steps (of 4 gathered rows) per pipeline stage: 16 rows in flight per stage; 32 for f > 64,
+// where the kernel runs one wave per SIMD (it needs the whole register file) and in-wave prefetch
+// is the only latency hiding
+template <int VW>
+struct StageGeo {
+    static constexpr int GS = VW >= 8 ? 8 : 4;
+    static constexpr int NG = 16 / GS;  // stages per 64-entry chunk
+};
 #ifndef ALS_SWEEP_WAVES
-#define ALS_SWEEP_WAVES 3  // waves per SIMD the per-row kernel's register budget is sized for
+#define ALS_SWEEP_WAVES 4  // waves per SIMD the per-row kernel's register budget is sized for (f <= 64)
 #endif
 
 template <int VW>
 struct Stage {
-    float v[GS][VW];
-    float w[GS];
-    float cw[GS];
+    float v[StageGeo<VW>::GS][VW];
+    float w[StageGeo<VW>::GS];
+    float cw[StageGeo<VW>::GS];
 };
 
 // ----------------------------------------------------------------------------- loads
@@ -133,6 +140,7 @@ template <int VW, bool VEC, bool FULL>
 __device__ __forceinline__ void issue(Stage<VW> &st, const int g, const uint32_t cur_off, const float cur_w,
                                       const float cur_cw, const float *__restrict__ Y, const int64_t ld, const int f,
                                       const int lane) {
+    constexpr int GS = StageGeo<VW>::GS;
     const int grp = lane >> 4, j = lane & 15;
 #pragma unroll
     for (int s = 0; s < GS; ++s) {
@@ -147,7 +155,7 @@ __device__ __forceinline__ void issue(Stage<VW> &st, const int g, const uint32_t
 template <int VW, bool WITH_B>
 __device__ __forceinline__ void compute(const Stage<VW> &st, f32x4 (&acc)[Geo<VW>::NT], float (&bacc)[VW]) {
 #pragma unroll
-    for (int s = 0; s < GS; ++s) {
+    for (int s = 0; s < StageGeo<VW>::GS; ++s) {
 #pragma unroll
         for (int ta = 0; ta < VW; ++ta) {
             const float a = st.w[s] * st.v[s][ta];
@@ -169,6 +177,7 @@ __device__ __forceinline__ void accumulate_range(f32x4 (&acc)[Geo<VW>::NT], floa
                                                  const int32_t *__restrict__ col, const float *__restrict__ val,
                                                  const int64_t s, const int64_t e, const float *__restrict__ Y,
                                                  const int64_t ld, const int f, const float alpha, const int lane) {
+    constexpr int GS = StageGeo<VW>::GS, NG = StageGeo<VW>::NG;
     Stage<VW> A, B;
     uint32_t cur_off, nxt_off = 0;
     float cur_w, cur_cw, nxt_w = 0.f, nxt_cw = 0.f;
@@ -197,20 +206,21 @@ __device__ __forceinline__ void accumulate_range(f32x4 (&acc)[Geo<VW>::NT], floa
         const bool more = nb < e;
         if (more) load_chunk(nb, nxt_off, nxt_w, nxt_cw);
         const int rem = more ? 64 : (int)(e - base);
-        const int ng = (rem + 15) >> 4;
-        if (ng > 1) issue<VW, VEC, FULL>(B, 1, cur_off, cur_w, cur_cw, Y, ld, f, lane);
-        compute<VW, GATHER>(A, acc, bacc);
-        if (ng > 2) issue<VW, VEC, FULL>(A, 2, cur_off, cur_w, cur_cw, Y, ld, f, lane);
-        if (ng > 1) compute<VW, GATHER>(B, acc, bacc);
-        if (ng > 3) issue<VW, VEC, FULL>(B, 3, cur_off, cur_w, cur_cw, Y, ld, f, lane);
-        if (ng > 2) compute<VW, GATHER>(A, acc, bacc);
-        if (more) {
-            cur_off = nxt_off;
-            cur_w = nxt_w;
-            cur_cw = nxt_cw;
-            issue<VW, VEC, FULL>(A, 0, cur_off, cur_w, cur_cw, Y, ld, f, lane);
+        const int ng = (rem + 4 * GS - 1) / (4 * GS);   // stages of this chunk that hold entries
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            Stage<VW> &cur = (g & 1) ? B : A;
+            Stage<VW> &nxt = (g & 1) ? A : B;
+            if (g + 1 < NG) {
+                if (ng > g + 1) issue<VW, VEC, FULL>(nxt, g + 1, cur_off, cur_w, cur_cw, Y, ld, f, lane);
+            } else if (more) {   // last stage of a full chunk: rotate to the prefetched chunk
+                cur_off = nxt_off;
+                cur_w = nxt_w;
+                cur_cw = nxt_cw;
+                issue<VW, VEC, FULL>(nxt, 0, cur_off, cur_w, cur_cw, Y, ld, f, lane);
+            }
+            if (ng > g) compute<VW, GATHER>(cur, acc, bacc);
         }
-        if (ng > 3) compute<VW, GATHER>(B, acc, bacc);
     }
 }
 
@@ -227,132 +237,6 @@ __device__ __forceinline__ void reduce_b(float (&bacc)[VW]) {
 // ----------------------------------------------------------------------------- solve
 __device__ __forceinline__ float readlane_f(const float x, const int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
-}
-
-// One step of the right-looking Cholesky (K is a compile-time constant so that every register
-// index is static; the steps are expanded with an index sequence, not a loop the optimizer may
-// decline to unroll).
-template <int FPAD, int K>
-__device__ __forceinline__ void chol_step(float (&a)[FPAD], float &bv, bool &bad, float *colbuf, float *zbuf,
-                                          float *rbuf, const int lane) {
-    const float akk = readlane_f(a[K], K);
-    bad = bad || !(akk > 0.f);
-    const float rinv = __builtin_amdgcn_rsqf(akk);
-    const float lik = a[K] * rinv;
-    a[K] = lik;
-    if constexpr (K + 1 < FPAD) a[K + 1] = fmaf(-lik, readlane_f(lik, K + 1), a[K + 1]);
-    colbuf[(K & 1) * 64 + lane] = lik;
-    const float zk = readlane_f(bv, K) * rinv;
-    zbuf[K] = zk;  // every lane stores the same value to the same word
-    rbuf[K] = rinv;
-    bv = fmaf(-lik, zk, bv);  // meaningful for lanes > K only
-#pragma unroll
-    for (int j4 = ((K + 2) & ~3); j4 < FPAD; j4 += 4) {
-        const f32x4 l4 = *reinterpret_cast<const f32x4 *>(colbuf + (K & 1) * 64 + j4);
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (j4 + c > K + 1) a[j4 + c] = fmaf(-lik, l4[c], a[j4 + c]);  // meaningful for lanes >= j only
-    }
-}
-template <int FPAD, int... Ks>
-__device__ __forceinline__ void chol_all(float (&a)[FPAD], float &bv, bool &bad, float *colbuf, float *zbuf,
-                                         float *rbuf, const int lane, std::integer_sequence<int, Ks...>) {
-    (chol_step<FPAD, Ks>(a, bv, bad, colbuf, zbuf, rbuf, lane), ...);
-}
-// Step of the back substitution L^T x = z for pivot KK = FPAD-1-K (a[k] holds L[k][lane]).
-template <int FPAD, int K>
-__device__ __forceinline__ void backsub_step(const float (&a)[FPAD], float &z, float &x, const float myrinv,
-                                             const int lane) {
-    constexpr int KK = FPAD - 1 - K;
-    const float xk = readlane_f(z, KK) * readlane_f(myrinv, KK);
-    if (lane == KK) x = xk;
-    if (lane < KK) z = fmaf(-a[KK], xk, z);
-}
-template <int FPAD, int... Ks>
-__device__ __forceinline__ void backsub_all(const float (&a)[FPAD], float &z, float &x, const float myrinv,
-                                            const int lane, std::integer_sequence<int, Ks...>) {
-    (backsub_step<FPAD, Ks>(a, z, x, myrinv, lane), ...);
-}
-
-// Solve (acc + gram_tiles) x = b for one row (f <= 64) and write x.  `lds` is this wave's
-// private Geo<VW>::TRI + FPAD floats.  Returns |x_old - x_new| summed over the row in lane 0.
-template <int VW>
-__device__ __forceinline__ float solve_row(const f32x4 (&acc)[Geo<VW>::NT], const float (&bacc)[VW],
-                                           const float *__restrict__ gtiles, float *lds, const int f,
-                                           float *__restrict__ xrow, int32_t *info, const int lane) {
-    constexpr int FPAD = Geo<VW>::FPAD;
-    constexpr int TRI = Geo<VW>::TRI;
-    const int grp = lane >> 4, j = lane & 15;
-
-    // 1. tile layout -> packed lower triangle in LDS (each unordered index pair written once)
-#pragma unroll
-    for (int ta = 0; ta < VW; ++ta) {
-#pragma unroll
-        for (int tb = ta; tb < VW; ++tb) {
-            const int t = tile_index(ta, tb, VW);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = grp * 4 + r;
-                const int ai = fidx<VW>(i, ta), bi = fidx<VW>(j, tb);
-                const float v = acc[t][r] + gtiles[(t * 4 + r) * 64 + lane];
-                const int hi = max(ai, bi), lo = min(ai, bi);
-                if (ta != tb || i >= j) lds[hi * (hi + 1) / 2 + lo] = v;
-            }
-        }
-    }
-    if (grp == 0) {
-#pragma unroll
-        for (int t = 0; t < VW; ++t) lds[TRI + fidx<VW>(j, t)] = bacc[t];
-    }
-    __builtin_amdgcn_wave_barrier();
-
-    // 2. one matrix row per lane
-    const int ic = min(lane, FPAD - 1);
-    const int rowoff = ic * (ic + 1) / 2;
-    float a[FPAD];
-#pragma unroll
-    for (int jj = 0; jj < FPAD; ++jj) a[jj] = lds[rowoff + jj];
-    float bv = lds[TRI + ic];
-    __builtin_amdgcn_wave_barrier();
-
-    // 3. right-looking Cholesky fused with the forward substitution L z = b.  Column k of L is
-    //    broadcast through LDS (every lane reads the same 16 bytes: 4 multipliers per ds_read);
-    //    only the multiplier of the NEXT pivot column goes through v_readlane, so the
-    //    pivot-to-pivot dependency chain does not wait for an LDS round trip.  Padded indices
-    //    (>= f) carry identity rows (gram_finalize_kernel puts 1 on their diagonal) and solve to 0,
-    //    so all FPAD steps run unconditionally.
-    float *colbuf = lds + TRI + FPAD;        // 2 x 64 floats, alternating per step
-    float *zbuf = lds + TRI;                 // z_k, then reused for nothing else (b was consumed above)
-    float *rbuf = lds + TRI + FPAD + 128;    // 1 / L[k][k]
-    bool bad = false;
-    chol_all<FPAD>(a, bv, bad, colbuf, zbuf, rbuf, lane, std::make_integer_sequence<int, FPAD>{});
-    __builtin_amdgcn_wave_barrier();
-
-    // 4. L -> LDS, read back transposed: a[k] = L[k][lane]
-#pragma unroll
-    for (int jj = 0; jj < FPAD; ++jj)
-        if (jj <= lane && lane < FPAD) lds[rowoff + jj] = a[jj];
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int jj = 0; jj < FPAD; ++jj) a[jj] = lds[jj * (jj + 1) / 2 + ic];
-    float z = zbuf[ic];
-    const float myrinv = rbuf[ic];
-    __builtin_amdgcn_wave_barrier();
-
-    // 5. back substitution L^T x = z
-    float x = 0.f;
-    backsub_all<FPAD>(a, z, x, myrinv, lane, std::make_integer_sequence<int, FPAD>{});
-
-    // 6. write back, |delta|
-    float d = 0.f;
-    if (lane < f) {
-        d = fabsf(xrow[lane] - x);
-        xrow[lane] = x;
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) d += __shfl_xor(d, o);
-    if (bad && lane == 0 && info) atomicAdd(info, 1);
-    return d;
 }
 
 // ----------------------------------------------------------------------------- blocked solve
@@ -548,11 +432,8 @@ struct SweepParams {
 };
 
 template <int VW, bool VEC, bool FULL>
-__global__ __launch_bounds__(64, ALS_SWEEP_WAVES) void sweep_items_kernel(const SweepParams p) {
+__global__ __launch_bounds__(64, (VW >= 8 ? 1 : ALS_SWEEP_WAVES)) void sweep_items_kernel(const SweepParams p) {
     using G = Geo<VW>;
-#ifdef ALS_SOLVE_LANEROW
-    __shared__ __attribute__((aligned(16))) float lds[G::TRI + G::FPAD + 128 + G::FPAD];
-#endif
     const int lane = threadIdx.x;
     const als_item_t it = p.items[blockIdx.x];
     const int row = it.row;
@@ -596,17 +477,13 @@ __global__ __launch_bounds__(64, ALS_SWEEP_WAVES) void sweep_items_kernel(const 
     } else {
 #else
     if (e > s) {
-#ifdef ALS_SOLVE_LANEROW
-        d = solve_row<VW>(acc, bacc, p.gtiles, lds, p.f, xrow, p.info, lane);
-#else
         d = solve_row_blocked<VW>(acc, bacc, p.gtiles, p.f, xrow, p.info, lane);
-#endif
     } else {
 #endif  // no entries: b = 0, so x = 0 exactly
         d = 0.f;
-        if (lane < p.f) {
-            d = fabsf(xrow[lane]);
-            xrow[lane] = 0.f;
+        for (int k = lane; k < p.f; k += 64) {
+            d += fabsf(xrow[k]);
+            xrow[k] = 0.f;
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) d += __shfl_xor(d, o);
@@ -617,9 +494,6 @@ __global__ __launch_bounds__(64, ALS_SWEEP_WAVES) void sweep_items_kernel(const 
 template <int VW>
 __global__ __launch_bounds__(64) void sweep_long_rows_kernel(const SweepParams p) {
     using G = Geo<VW>;
-#ifdef ALS_SOLVE_LANEROW
-    __shared__ __attribute__((aligned(16))) float lds[G::TRI + G::FPAD + 128 + G::FPAD];
-#endif
     const int lane = threadIdx.x;
     const als_long_row_t lr = p.long_rows[blockIdx.x];
     f32x4 acc[G::NT];
@@ -642,11 +516,7 @@ __global__ __launch_bounds__(64) void sweep_long_rows_kernel(const SweepParams p
     }
     const int row = lr.row;
     const int64_t xr = p.row_ids ? p.row_ids[row] : (int64_t)row;
-#ifdef ALS_SOLVE_LANEROW
-    const float d = solve_row<VW>(acc, bacc, p.gtiles, lds, p.f, p.X + xr * p.ldx, p.info, lane);
-#else
     const float d = solve_row_blocked<VW>(acc, bacc, p.gtiles, p.f, p.X + xr * p.ldx, p.info, lane);
-#endif
     if (lane == 0) p.rowdiff[row] = d;
 }
 
@@ -918,7 +788,7 @@ int32_t als_gram_partials_f32(const float *Y, int64_t row_begin, int64_t row_end
         case 1: return gram_partials_impl<1>(Y, row_begin, row_end, f, ldy, super_out, workspace, st);
         case 2: return gram_partials_impl<2>(Y, row_begin, row_end, f, ldy, super_out, workspace, st);
         case 4: return gram_partials_impl<4>(Y, row_begin, row_end, f, ldy, super_out, workspace, st);
-        default: return fail(ALS_ERR_UNSUPPORTED, "f=%d: exact path supports f <= 64 in this build", f);
+        default: return gram_partials_impl<8>(Y, row_begin, row_end, f, ldy, super_out, workspace, st);
     }
 }
 
@@ -934,7 +804,7 @@ int32_t als_gram_finalize_f32(const float *super_in, int64_t n_super, int32_t f,
         case 1: hipLaunchKernelGGL(gram_finalize_kernel<1>, grid, block, 0, st, super_in, n_super, f, lamb, gram_out, tiles_out); break;
         case 2: hipLaunchKernelGGL(gram_finalize_kernel<2>, grid, block, 0, st, super_in, n_super, f, lamb, gram_out, tiles_out); break;
         case 4: hipLaunchKernelGGL(gram_finalize_kernel<4>, grid, block, 0, st, super_in, n_super, f, lamb, gram_out, tiles_out); break;
-        default: return fail(ALS_ERR_UNSUPPORTED, "f=%d: exact path supports f <= 64 in this build", f);
+        default: hipLaunchKernelGGL(gram_finalize_kernel<8>, grid, block, 0, st, super_in, n_super, f, lamb, gram_out, tiles_out); break;
     }
     ALS_HIP_CHECK(hipGetLastError());
     return ALS_OK;
@@ -1007,7 +877,7 @@ int32_t als_half_sweep_csr_f32(const int64_t *rowptr, const int32_t *col, const 
         case 1: return half_sweep_impl<1>(p, n_rows, n_items, n_long, absdiff_out, diff_partials, vec, st);
         case 2: return half_sweep_impl<2>(p, n_rows, n_items, n_long, absdiff_out, diff_partials, vec, st);
         case 4: return half_sweep_impl<4>(p, n_rows, n_items, n_long, absdiff_out, diff_partials, vec, st);
-        default: return fail(ALS_ERR_UNSUPPORTED, "f=%d: exact path supports f <= 64 in this build", f);
+        default: return half_sweep_impl<8>(p, n_rows, n_items, n_long, absdiff_out, diff_partials, vec, st);
     }
 }
 

@@ -49,7 +49,7 @@ def _sweep(ra, ptr, ind, dat, shape, Yfix, Xold, lamb, alpha, chunk_nnz=2048, ro
 
 
 # ----------------------------------------------------------------------------- gram
-@pytest.mark.parametrize("f", [5, 8, 16, 20, 32, 50, 64])
+@pytest.mark.parametrize("f", [5, 8, 16, 20, 32, 50, 64, 100, 128])
 @pytest.mark.parametrize("n", [1, 3, 100, 1023, 1025, 70001])
 def test_gram_matches_numpy(ra, f, n):
     rng = np.random.default_rng(f * 1000 + n)
@@ -149,7 +149,7 @@ def _random_csr(rng, N, M, avg, maxlen):
     return ptr, ind, dat
 
 
-@pytest.mark.parametrize("f", [20, 64])
+@pytest.mark.parametrize("f", [20, 50, 64, 96, 128])
 def test_random_matrix_vs_c_oracle(ra, f):
     rng = np.random.default_rng(77 + f)
     N, M = 3000, 5000
