@@ -73,17 +73,21 @@ __host__ __device__ __forceinline__ constexpr int fidx(int j, int t) {
     else return (t < 4) ? 4 * j + t : 64 + 4 * j + (t - 4);
 }
 
-// k-steps (of 4 gathered rows) per pipeline stage: 16 rows in flight per stage; 32 for f > 64,
-// where the kernel runs one wave per SIMD (it needs the whole register file) and in-wave prefetch
-// is the only latency hiding
-template <int VW>
-struct StageGeo {
-    static constexpr int GS = VW >= 8 ? 8 : 4;
-    static constexpr int NG = 16 / GS;  // stages per 64-entry chunk
-};
+#ifndef ALS_SWEEP_WAVES_F128
+#define ALS_SWEEP_WAVES_F128 2  // same for 64 < f <= 128 (144 accumulator registers)
+#endif
+#ifndef ALS_STAGE_F128
+#define ALS_STAGE_F128 4
+#endif
 #ifndef ALS_SWEEP_WAVES
 #define ALS_SWEEP_WAVES 4  // waves per SIMD the per-row kernel's register budget is sized for (f <= 64)
 #endif
+// k-steps (of 4 gathered rows) per pipeline stage (16 rows in flight per stage)
+template <int VW>
+struct StageGeo {
+    static constexpr int GS = VW >= 8 ? ALS_STAGE_F128 : 4;
+    static constexpr int NG = 16 / GS;  // stages per 64-entry chunk
+};
 
 template <int VW>
 struct Stage {
@@ -309,6 +313,31 @@ __device__ __forceinline__ f32x4 tile_x_v(const f32x4 &X, const float vcol) {
     return o;
 }
 
+// d += row_newbcast:K(d) * nv as ONE instruction (v_fmac_f32 with a DPP source).  hipcc keeps a
+// v_mov_b32_dpp + v_fmac_f32 pair for the builtin form, and half of the solve's vector instructions
+// are these.  The compiler does not see inside an asm statement, so the DPP read hazard (a VGPR
+// written by a vector instruction may be read through DPP two wait states later at the earliest)
+// is handled here: the statements are volatile, hence stay in program order, and every register
+// is touched once per elimination step (8 statements apart); GUARD adds the wait states for the
+// one step whose source was last written by compiler-scheduled code.
+#define ALS_FMAC_BCAST_CASE(n)                                                                            \
+    if constexpr (K == n) {                                                                               \
+        if constexpr (GUARD)                                                                              \
+            asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 row_newbcast:" #n " row_mask:0xf bank_mask:0xf" \
+                         : "+v"(d) : "v"(nv));                                                            \
+        else                                                                                              \
+            asm volatile("v_fmac_f32_dpp %0, %0, %1 row_newbcast:" #n " row_mask:0xf bank_mask:0xf"       \
+                         : "+v"(d) : "v"(nv));                                                            \
+    }
+template <int K, bool GUARD>
+__device__ __forceinline__ void fmac_bcast(float &d, const float nv) {
+    ALS_FMAC_BCAST_CASE(0) ALS_FMAC_BCAST_CASE(1) ALS_FMAC_BCAST_CASE(2) ALS_FMAC_BCAST_CASE(3)
+    ALS_FMAC_BCAST_CASE(4) ALS_FMAC_BCAST_CASE(5) ALS_FMAC_BCAST_CASE(6) ALS_FMAC_BCAST_CASE(7)
+    ALS_FMAC_BCAST_CASE(8) ALS_FMAC_BCAST_CASE(9) ALS_FMAC_BCAST_CASE(10) ALS_FMAC_BCAST_CASE(11)
+    ALS_FMAC_BCAST_CASE(12) ALS_FMAC_BCAST_CASE(13) ALS_FMAC_BCAST_CASE(14) ALS_FMAC_BCAST_CASE(15)
+}
+#undef ALS_FMAC_BCAST_CASE
+
 // One elimination step on a diagonal tile D (pivot K) and on N, which accumulates the inverse of
 // the unit upper factor by the mirrored column operations.
 template <int K>
@@ -319,10 +348,20 @@ __device__ __forceinline__ void diag_step(f32x4 &D, f32x4 &N, const int c) {
     rd = rd * fmaf(-d, rd, 2.0f);                        // one Newton step on the reciprocal
     const float rowk = __shfl(D[reg], src + c);          // row K of D in every lane group
     const float nv = (c > K) ? -(rowk * rd) : 0.f;
+    if constexpr (K == 0) {   // sources come straight from compiler-scheduled code (MFMA results, N's init)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        D[r] = fmaf(dpp_f<0x150 + K>(D[r]), nv, D[r]);   // row_newbcast:K = D[4g+r][K]
-        N[r] = fmaf(dpp_f<0x150 + K>(N[r]), nv, N[r]);
+        for (int r = 0; r < 4; ++r) {
+            D[r] = fmaf(dpp_f<0x150 + K>(D[r]), nv, D[r]);   // row_newbcast:K = D[4g+r][K]
+            N[r] = fmaf(dpp_f<0x150 + K>(N[r]), nv, N[r]);
+        }
+    } else {
+        float d0 = D[0], d1 = D[1], d2 = D[2], d3 = D[3], n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3];
+        fmac_bcast<K, K == 1>(d0, nv); fmac_bcast<K, K == 1>(d1, nv);
+        fmac_bcast<K, K == 1>(d2, nv); fmac_bcast<K, K == 1>(d3, nv);
+        fmac_bcast<K, K == 1>(n0, nv); fmac_bcast<K, K == 1>(n1, nv);
+        fmac_bcast<K, K == 1>(n2, nv); fmac_bcast<K, K == 1>(n3, nv);
+        D = f32x4{d0, d1, d2, d3};
+        N = f32x4{n0, n1, n2, n3};
     }
 }
 template <int... Ks>
@@ -351,34 +390,37 @@ __device__ __forceinline__ f32x4 diag_inverse_factor(f32x4 D, const int lane, bo
 // block (destroyed).  x: column-indexed solution per block.  Returns false if a pivot was <= 0.
 template <int VW>
 __device__ __forceinline__ bool blocked_solve(f32x4 (&T)[Geo<VW>::NT], float (&b)[VW], float (&x)[VW], const int lane) {
-    f32x4 Xd[VW], zrow[VW];
+    float zcol[VW];
     bool ok = true;
 #pragma unroll
     for (int kb = 0; kb < VW; ++kb) {
+        // the diagonal tile is dead once factored: its slot keeps X = U_kk^{-1} for the back substitution
         const f32x4 X = diag_inverse_factor(T[tile_index(kb, kb, VW)], lane, ok);
-        Xd[kb] = X;
+        T[tile_index(kb, kb, VW)] = X;
 #pragma unroll
         for (int jb = kb + 1; jb < VW; ++jb) {
             f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f};
             tile_xtz<false>(X, T[tile_index(kb, jb, VW)], u);
             T[tile_index(kb, jb, VW)] = u;
         }
-        const float z = tile_xt_v(X, vec_col_to_row(b[kb], lane));     // z_kb = U_d^{-T} b_kb
-        zrow[kb] = vec_col_to_row(z, lane);
+        zcol[kb] = tile_xt_v(X, vec_col_to_row(b[kb], lane));          // z_kb = U_kk^{-T} b_kb
+        const f32x4 zrow = vec_col_to_row(zcol[kb], lane);
 #pragma unroll
         for (int ib = kb + 1; ib < VW; ++ib) {
             const f32x4 Ui = T[tile_index(kb, ib, VW)];
+            const f32x4 nUi = -Ui;
 #pragma unroll
-            for (int jb = ib; jb < VW; ++jb) tile_xtz<true>(Ui, T[tile_index(kb, jb, VW)], T[tile_index(ib, jb, VW)]);
-            b[ib] -= tile_xt_v(Ui, zrow[kb]);
+            for (int jb = ib; jb < VW; ++jb) tile_xtz<false>(nUi, T[tile_index(kb, jb, VW)], T[tile_index(ib, jb, VW)]);
+            b[ib] -= tile_xt_v(Ui, zrow);
         }
+        __builtin_amdgcn_sched_barrier(0);   // block steps stay in order: bounds the live ranges
     }
 #pragma unroll
     for (int kb = VW - 1; kb >= 0; --kb) {
-        f32x4 acc = zrow[kb];
+        f32x4 acc = vec_col_to_row(zcol[kb], lane);
 #pragma unroll
         for (int jb = kb + 1; jb < VW; ++jb) acc -= tile_x_v(T[tile_index(kb, jb, VW)], x[jb]);
-        x[kb] = vec_row_to_col(tile_x_v(Xd[kb], vec_row_to_col(acc, lane)), lane);
+        x[kb] = vec_row_to_col(tile_x_v(T[tile_index(kb, kb, VW)], vec_row_to_col(acc, lane)), lane);
     }
     return ok;
 }
@@ -389,9 +431,12 @@ __device__ __forceinline__ float solve_row_blocked(f32x4 (&acc)[Geo<VW>::NT], fl
                                                    const float *__restrict__ gtiles, const int f,
                                                    float *__restrict__ xrow, int32_t *info, const int lane) {
 #pragma unroll
-    for (int t = 0; t < Geo<VW>::NT; ++t)
+    for (int t = 0; t < Geo<VW>::NT; ++t) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[t][r] += gtiles[(t * 4 + r) * 64 + lane];
+        // keep the scheduler from hoisting all NT*4 loads to the top (they would need as many registers)
+        if (t % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+    }
     float x[VW];
     const bool ok = blocked_solve<VW>(acc, bacc, x, lane);
     const int j = lane & 15;
@@ -432,7 +477,7 @@ struct SweepParams {
 };
 
 template <int VW, bool VEC, bool FULL>
-__global__ __launch_bounds__(64, (VW >= 8 ? 1 : ALS_SWEEP_WAVES)) void sweep_items_kernel(const SweepParams p) {
+__global__ __launch_bounds__(64, (VW >= 8 ? ALS_SWEEP_WAVES_F128 : ALS_SWEEP_WAVES)) void sweep_items_kernel(const SweepParams p) {
     using G = Geo<VW>;
     const int lane = threadIdx.x;
     const als_item_t it = p.items[blockIdx.x];
@@ -491,6 +536,21 @@ __global__ __launch_bounds__(64, (VW >= 8 ? 1 : ALS_SWEEP_WAVES)) void sweep_ite
     if (lane == 0) p.rowdiff[row] = d;
 }
 
+// Adds the chunk partials of every long row into the row's first slot, element by element in
+// chunk order (so the sum is the same left-to-right chain for any launch geometry).
+// grid = (n_long, ceil(elems / 256)).
+__global__ __launch_bounds__(256) void sum_slots_kernel(float *__restrict__ partials,
+                                                       const als_long_row_t *__restrict__ long_rows,
+                                                       const int elems) {
+    const als_long_row_t lr = long_rows[blockIdx.x];
+    const int e = blockIdx.y * 256 + threadIdx.x;
+    if (e >= elems) return;
+    float *P = partials + (int64_t)lr.first_slot * elems + e;
+    float acc = P[0];
+    for (int c = 1; c < lr.n_chunks; ++c) acc += P[(int64_t)c * elems];
+    P[0] = acc;
+}
+
 template <int VW>
 __global__ __launch_bounds__(64) void sweep_long_rows_kernel(const SweepParams p) {
     using G = Geo<VW>;
@@ -505,15 +565,6 @@ __global__ __launch_bounds__(64) void sweep_long_rows_kernel(const SweepParams p
         for (int r = 0; r < 4; ++r) acc[t][r] = P[(t * 4 + r) * 64 + lane];
 #pragma unroll
     for (int t = 0; t < VW; ++t) bacc[t] = P[(G::TQ + t) * 64 + lane];
-    for (int c = 1; c < lr.n_chunks; ++c) {
-        P += G::PQ * 64;
-#pragma unroll
-        for (int t = 0; t < G::NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[t][r] += P[(t * 4 + r) * 64 + lane];
-#pragma unroll
-        for (int t = 0; t < VW; ++t) bacc[t] += P[(G::TQ + t) * 64 + lane];
-    }
     const int row = lr.row;
     const int64_t xr = p.row_ids ? p.row_ids[row] : (int64_t)row;
     const float d = solve_row_blocked<VW>(acc, bacc, p.gtiles, p.f, p.X + xr * p.ldx, p.info, lane);
@@ -663,6 +714,10 @@ static int32_t half_sweep_impl(const SweepParams &p, int64_t n_rows, int64_t n_i
         if (tap1) ALS_HIP_CHECK(hipEventRecord(tap1, st));
     }
     if (n_long > 0) {
+        const int elems = Geo<VW>::PQ * 64;
+        hipLaunchKernelGGL(sum_slots_kernel, dim3((unsigned)n_long, (unsigned)((elems + 255) / 256)), dim3(256), 0, st,
+                           p.partials, p.long_rows, elems);
+        ALS_HIP_CHECK(hipGetLastError());
         hipLaunchKernelGGL(sweep_long_rows_kernel<VW>, dim3((unsigned)n_long), dim3(64), 0, st, p);
         ALS_HIP_CHECK(hipGetLastError());
     }
