@@ -74,10 +74,10 @@ __host__ __device__ __forceinline__ constexpr int fidx(int j, int t) {
 }
 
 #ifndef ALS_SWEEP_WAVES_F128
-#define ALS_SWEEP_WAVES_F128 2  // same for 64 < f <= 128 (144 accumulator registers)
+#define ALS_SWEEP_WAVES_F128 1  // 64 < f <= 128: 144 accumulator registers + the stages need > 256 registers
 #endif
 #ifndef ALS_STAGE_F128
-#define ALS_STAGE_F128 4
+#define ALS_STAGE_F128 8  // with one wave per SIMD, in-wave prefetch (32 rows per stage) is the latency hiding
 #endif
 #ifndef ALS_SWEEP_WAVES
 #define ALS_SWEEP_WAVES 4  // waves per SIMD the per-row kernel's register budget is sized for (f <= 64)
