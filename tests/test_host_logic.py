@@ -101,3 +101,14 @@ def test_synthetic_generator_is_canonical_and_seeded():
         assert np.all(np.diff(c) > 0)                                      # sorted, duplicate free
     A = data.to_scipy(U, (300, 200)); At = data.to_scipy(Ut, (200, 300))
     assert (A.T != At).nnz == 0
+
+
+def test_blocked_solve_index_logic_in_emulation():
+    """The lane/register index maps of the in-register block Cholesky (MFMA accumulator layout, DPP
+    row broadcasts, XtZ tile products), emulated in numpy lane by lane, solve SPD systems for every
+    tile-grid size the kernels instantiate."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("emul", os.path.join(ROOT, "tools", "emul_blocked_solve.py"))
+    emul = importlib.util.module_from_spec(spec); spec.loader.exec_module(emul)
+    for VW, f in [(1, 5), (2, 20), (4, 64), (8, 100)]:
+        assert emul.run(VW, f, seed=VW) < 2e-4
