@@ -70,9 +70,10 @@ def als_update_cache(Y, lamb, cache=None, group=None, backend=ops):
     elems = mine.shape[1]
     send = torch.zeros((cnt_max, elems), dtype=mine.dtype, device=Y.device)
     send[: mine.shape[0]] = mine
-    recv = torch.empty((world * cnt_max, elems), dtype=mine.dtype, device=Y.device)
-    torch.distributed.all_gather_into_tensor(recv, send, group=group)
-    parts = [recv[r * cnt_max: r * cnt_max + (cuts[r + 1] - cuts[r])] for r in range(world)]
+    recv = [torch.empty((cnt_max, elems), dtype=mine.dtype, device=Y.device) for _ in range(world)]
+    _drain_for_host_staged_backend(Y, group)
+    torch.distributed.all_gather(recv, send, group=group)       # a few KB per rank
+    parts = [recv[r][: cuts[r + 1] - cuts[r]] for r in range(world)]
     return backend.gram_finalize(torch.cat(parts, 0).contiguous(), f, lamb, out=cache)
 
 
@@ -83,9 +84,19 @@ def run_als_epoch(csr, X, Y, cache, alpha, absdiff=None, info=None, backend=ops)
     return backend.half_sweep(csr, Y, cache, X, alpha, absdiff=absdiff, info=info)
 
 
+def _drain_for_host_staged_backend(T, group):
+    """RCCL collectives are stream ordered.  gloo stages device tensors through the host on streams
+    of its own; observed on MI355X: with kernels still queued on the current stream, two ranks
+    sharing one GPU can wait on each other forever.  Drain the device first in that case (tests
+    and rehearsals only; "nccl" never takes this branch)."""
+    if T.is_cuda and torch.distributed.get_backend(group) != "nccl":
+        torch.cuda.synchronize(T.device)
+
+
 def _all_gather_rows(T, bounds, rank, group):
     """In-place all-gather of the row shards [bounds[r], bounds[r+1]) of the replicated T."""
     world = len(bounds) - 1
+    _drain_for_host_staged_backend(T, group)
     sizes = [int(bounds[r + 1] - bounds[r]) for r in range(world)]
     if len(set(sizes)) == 1 and T.is_contiguous() and sizes[0] * world == T.shape[0]:
         torch.distributed.all_gather_into_tensor(T, T[bounds[rank]:bounds[rank + 1]], group=group)
