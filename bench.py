@@ -114,11 +114,21 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    # ALS_BENCH_REHEARSAL=1: every rank on GPU 0 with gloo collectives, to walk the multi-rank code
+    # path on a one-GPU box (its timings mean nothing)
+    rehearsal = bool(os.environ.get("ALS_BENCH_REHEARSAL"))
+    if rehearsal:
+        local = 0
+        import faulthandler
+        faulthandler.dump_traceback_later(60, exit=True)      # a stuck rehearsal names where it is stuck
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     group = None
     if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=dev)
         group = torch.distributed.group.WORLD
 
     from recommender_amd import data, ops
@@ -146,18 +156,19 @@ def main():
 
     for _ in range(args.warmup):
         eng.step()
-    # taps: events around the gather/accumulate kernel of each half-sweep, on the launch stream
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
-    for row in evs:
-        for e in row:
-            e.record()          # materialise the handles
+    # taps: events around every launch of the gather/accumulate kernel, on the launch stream
+    # (the user sweep is several launches when its all-gather is overlapped chunk by chunk)
+    launches_per_step = (len(eng._parts()) if world > 1 else 1) + 1
+    pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * launches_per_step * args.steps)]
+    for e in pool:
+        e.record()          # materialise the handles
     sync()
-    state = {"k": 0}
+    taps = {"users": [], "items": []}
 
     def tap(which):
-        k = state["k"]; state["k"] += 1
-        e0, e1 = evs[k // 2][(k % 2) * 2], evs[k // 2][(k % 2) * 2 + 1]
+        e0, e1 = pool.pop(), pool.pop()
         lib.als_profile_tap_next_sweep(ctypes.c_void_p(e0.cuda_event), ctypes.c_void_p(e1.cuda_event))
+        taps[which].append((e0, e1))
 
     eng.pre_sweep_hook = tap
     sync()
@@ -168,7 +179,7 @@ def main():
     dt = time.perf_counter() - t0
     eng.pre_sweep_hook = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     if int(eng.info.item()) != 0 and not os.environ.get("ALS_BENCH_IGNORE_INFO"):   # (timing-only ablation builds set it)
@@ -176,8 +187,8 @@ def main():
 
     # dominant kernel: the per-row gather/accumulate(+solve) kernel; algorithmic bytes per launch =
     # nnz*(4 col + 4 val + 4f gathered row) + n_rows*(8 rowptr + 4f written row)
-    ku = sum(r[0].elapsed_time(r[1]) for r in evs) / args.steps
-    ki = sum(r[2].elapsed_time(r[3]) for r in evs) / args.steps
+    ku = sum(e0.elapsed_time(e1) for e0, e1 in taps["users"]) / args.steps
+    ki = sum(e0.elapsed_time(e1) for e0, e1 in taps["items"]) / args.steps
     bytes_u = csr_u.nnz * (8 + 4 * f) + csr_u.shape[0] * (8 + 4 * f)
     bytes_i = csr_i.nnz * (8 + 4 * f) + csr_i.shape[0] * (8 + 4 * f)
     achieved = (bytes_u + bytes_i) / ((ku + ki) * 1e-3) / 1e9

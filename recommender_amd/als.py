@@ -68,13 +68,13 @@ def als_update_cache(Y, lamb, cache=None, group=None, backend=ops):
     mine = backend.gram_partials(Y, s0 * _lib.GRAM_SUPER_ROWS, min(n, s1 * _lib.GRAM_SUPER_ROWS))
     cnt_max = max(cuts[r + 1] - cuts[r] for r in range(world))
     elems = mine.shape[1]
-    send = torch.zeros((cnt_max, elems), dtype=mine.dtype, device=Y.device)
+    xdev = "cpu" if _host_staged(Y, group) else Y.device
+    send = torch.zeros((cnt_max, elems), dtype=mine.dtype, device=xdev)
     send[: mine.shape[0]] = mine
-    recv = [torch.empty((cnt_max, elems), dtype=mine.dtype, device=Y.device) for _ in range(world)]
-    _drain_for_host_staged_backend(Y, group)
+    recv = [torch.empty((cnt_max, elems), dtype=mine.dtype, device=xdev) for _ in range(world)]
     torch.distributed.all_gather(recv, send, group=group)       # a few KB per rank
     parts = [recv[r][: cuts[r + 1] - cuts[r]] for r in range(world)]
-    return backend.gram_finalize(torch.cat(parts, 0).contiguous(), f, lamb, out=cache)
+    return backend.gram_finalize(torch.cat(parts, 0).to(Y.device).contiguous(), f, lamb, out=cache)
 
 
 def run_als_epoch(csr, X, Y, cache, alpha, absdiff=None, info=None, backend=ops):
@@ -84,27 +84,50 @@ def run_als_epoch(csr, X, Y, cache, alpha, absdiff=None, info=None, backend=ops)
     return backend.half_sweep(csr, Y, cache, X, alpha, absdiff=absdiff, info=info)
 
 
-def _drain_for_host_staged_backend(T, group):
-    """RCCL collectives are stream ordered.  gloo stages device tensors through the host on streams
-    of its own; observed on MI355X: with kernels still queued on the current stream, two ranks
-    sharing one GPU can wait on each other forever.  Drain the device first in that case (tests
-    and rehearsals only; "nccl" never takes this branch)."""
-    if T.is_cuda and torch.distributed.get_backend(group) != "nccl":
-        torch.cuda.synchronize(T.device)
+def _host_staged(T, group):
+    """RCCL ("nccl") moves device tensors directly and in stream order.  Any other backend (gloo in
+    tests and one-GPU rehearsals) gets host tensors: its own device-tensor path hung intermittently
+    with two ranks sharing one MI355X."""
+    return T.is_cuda and torch.distributed.get_backend(group) != "nccl"
+
+
+def _all_gather_row_blocks(T, starts, sizes, rank, group):
+    """All-gather of one row block per rank of the replicated T, in place: rank r owns
+    T[starts[r] : starts[r] + sizes[r]] and every rank ends up with all of them.  One collective
+    whatever the sizes: unequal blocks travel padded to the longest."""
+    world = len(sizes)
+    if max(sizes) == 0:
+        return
+    mine = T[starts[rank]: starts[rank] + sizes[rank]]
+    equal = len(set(sizes)) == 1
+    host = _host_staged(T, group)
+    if equal and not host:
+        if T.is_contiguous() and all(starts[r] == r * sizes[0] for r in range(world)) and sizes[0] * world == T.shape[0]:
+            torch.distributed.all_gather_into_tensor(T, mine, group=group)      # blocks tile T: no staging at all
+        else:
+            torch.distributed.all_gather([T[starts[r]: starts[r] + sizes[r]] for r in range(world)], mine, group=group)
+        return
+    cap = max(sizes)
+    send = torch.zeros((cap,) + tuple(T.shape[1:]), dtype=T.dtype, device="cpu" if host else T.device)
+    send[: sizes[rank]] = mine
+    recv = [torch.empty_like(send) for _ in range(world)]
+    torch.distributed.all_gather(recv, send, group=group)
+    for r in range(world):
+        if r != rank and sizes[r]:
+            T[starts[r]: starts[r] + sizes[r]] = recv[r][: sizes[r]]
 
 
 def _all_gather_rows(T, bounds, rank, group):
     """In-place all-gather of the row shards [bounds[r], bounds[r+1]) of the replicated T."""
     world = len(bounds) - 1
-    _drain_for_host_staged_backend(T, group)
-    sizes = [int(bounds[r + 1] - bounds[r]) for r in range(world)]
-    if len(set(sizes)) == 1 and T.is_contiguous() and sizes[0] * world == T.shape[0]:
-        torch.distributed.all_gather_into_tensor(T, T[bounds[rank]:bounds[rank + 1]], group=group)
-        return
-    for r in range(world):
-        if sizes[r]:
-            torch.distributed.broadcast(T[bounds[r]:bounds[r + 1]], src=torch.distributed.get_global_rank(group, r)
-                                        if group is not None else r, group=group)
+    _all_gather_row_blocks(T, [int(bounds[r]) for r in range(world)],
+                           [int(bounds[r + 1] - bounds[r]) for r in range(world)], rank, group)
+
+
+def _chunk_cuts(n, parts):
+    """Boundaries of `parts` near-equal row chunks of a shard of n rows (every rank can compute
+    every other rank's cuts from the shard boundaries alone)."""
+    return [(n * c) // parts for c in range(parts + 1)]
 
 
 # ----------------------------------------------------------------------------- engine
@@ -118,7 +141,7 @@ class ALSEngine:
     """
 
     def __init__(self, csr_users, csr_items, X, Y, lamb, alpha, user_bounds=None, item_bounds=None, group=None,
-                 backend=ops):
+                 backend=ops, overlap_chunks=None):
         self.group = group
         self.backend = backend      # the HIP operators; tests inject a CPU stand-in to exercise the sharding logic
         self.world = torch.distributed.get_world_size(group) if group is not None else 1
@@ -144,19 +167,73 @@ class ALSEngine:
         self._dY = torch.zeros(1, dtype=torch.float64, device=X.device)
         self.info = torch.zeros(1, dtype=torch.int32, device=X.device)
         self.trace = []
-        self.pre_sweep_hook = None     # callable("users" | "items"), run just before each half-sweep launch
+        self.pre_sweep_hook = None     # callable("users" | "items"), run just before each sweep launch
+        # Multi-GPU: the user sweep runs as `overlap_chunks` row chunks; the all-gather of chunk c
+        # runs on a side stream beside the sweep of chunk c+1, so only the last chunk's exchange is
+        # exposed.  A row's result does not depend on which launch computes it, so factors are
+        # unchanged bit for bit.  (X is the large factor; Y is exchanged in one piece.)
+        if overlap_chunks is None:
+            overlap_chunks = 4 if self.world > 1 else 1
+        self.overlap_chunks = max(1, int(overlap_chunks))      # the same on every rank
+        self._user_parts = None
+        self._side = None
+
+    def _parts(self):
+        """[(row0, row1, csr chunk or None if empty, |delta| buffer)], chunk c of this rank's user shard."""
+        if self._user_parts is None:
+            n = self.csr_users.shape[0]
+            if self.overlap_chunks == 1:
+                self._user_parts = [(0, n, self.csr_users if n else None, self._dX)]
+            else:
+                cuts = _chunk_cuts(n, self.overlap_chunks)
+                self._user_parts = [
+                    (cuts[c], cuts[c + 1],
+                     self.csr_users.row_range(cuts[c], cuts[c + 1]) if cuts[c + 1] > cuts[c] else None,
+                     torch.zeros(1, dtype=torch.float64, device=self.X.device))
+                    for c in range(self.overlap_chunks)]
+        return self._user_parts
+
+    def _sweep_users(self):
+        u0 = self.user_bounds[self.rank]
+        parts = self._parts()
+        chunked = self.world > 1 and self.overlap_chunks > 1
+        on_gpu = self.X.is_cuda
+        if chunked and on_gpu and self._side is None:
+            self._side = torch.cuda.Stream(device=self.X.device)
+        done = []
+        for c, (r0, r1, csr, dbuf) in enumerate(parts):
+            if csr is not None:
+                if self.pre_sweep_hook: self.pre_sweep_hook("users")
+                run_als_epoch(csr, self.X[u0 + r0:u0 + r1], self.Y, self.cache_Y, self.alpha, dbuf, self.info,
+                              self.backend)
+            else:
+                dbuf.zero_()
+            if not chunked:
+                continue
+            # chunk c of every rank: rows [bounds[r] + cuts_r[c], bounds[r] + cuts_r[c+1])
+            starts, sizes = [], []
+            for r in range(self.world):
+                cuts = _chunk_cuts(self.user_bounds[r + 1] - self.user_bounds[r], self.overlap_chunks)
+                starts.append(self.user_bounds[r] + cuts[c]); sizes.append(cuts[c + 1] - cuts[c])
+            if on_gpu:
+                self._side.wait_stream(torch.cuda.current_stream(self.X.device))
+                with torch.cuda.stream(self._side):
+                    _all_gather_row_blocks(self.X, starts, sizes, self.rank, self.group)
+                    done.append(self._side.record_event())
+            else:
+                _all_gather_row_blocks(self.X, starts, sizes, self.rank, self.group)
+        for ev in done:
+            torch.cuda.current_stream(self.X.device).wait_event(ev)
+        if len(parts) > 1:
+            torch.sum(torch.cat([p[3] for p in parts]), 0, keepdim=True, out=self._dX)
+        if self.world > 1 and not chunked:
+            _all_gather_rows(self.X[: self.n_users], self.user_bounds, self.rank, self.group)
 
     # one ALS iteration = X half-sweep + Y half-sweep, Gram refreshes included
     def step(self):
-        u0, u1 = self.user_bounds[self.rank], self.user_bounds[self.rank + 1]
         i0, i1 = self.item_bounds[self.rank], self.item_bounds[self.rank + 1]
         als_update_cache(self.Y, self.lamb, self.cache_Y, self.group, self.backend)
-        if u1 > u0:
-            if self.pre_sweep_hook: self.pre_sweep_hook("users")
-            run_als_epoch(self.csr_users, self.X[u0:u1], self.Y, self.cache_Y, self.alpha, self._dX, self.info,
-                          self.backend)
-        if self.world > 1:
-            _all_gather_rows(self.X[: self.n_users], self.user_bounds, self.rank, self.group)
+        self._sweep_users()
         als_update_cache(self.X, self.lamb, self.cache_X, self.group, self.backend)
         if i1 > i0:
             if self.pre_sweep_hook: self.pre_sweep_hook("items")
@@ -170,6 +247,8 @@ class ALSEngine:
         Synchronises with the device."""
         d = torch.stack([self._dX[0] / (self.n_users * self.f), self._dY[0] / (self.n_items * self.f)])
         if self.world > 1:
+            if _host_staged(d, self.group):
+                d = d.cpu()
             torch.distributed.all_reduce(d, group=self.group)
         return float(d.sum().item())
 

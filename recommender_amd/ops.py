@@ -117,6 +117,18 @@ class DeviceCSR:
         U.sort_indices()
         return cls(U.indptr, U.indices, U.data, U.shape, device, chunk_nnz, row_ids)
 
+    def row_range(self, r0, r1):
+        """Rows [r0, r1) as a DeviceCSR of their own (own schedule and workspace; the column and
+        value arrays are views of this one's)."""
+        r0, r1 = int(r0), int(r1)
+        if not (0 <= r0 < r1 <= self.shape[0]):
+            raise ValueError("bad row range")
+        ptr = self.rowptr[r0:r1 + 1]
+        lo, hi = int(ptr[0]), int(ptr[-1])
+        ids = None if self.row_ids is None else self.row_ids[r0:r1].cpu().numpy()
+        return DeviceCSR(ptr - lo, self.col[lo:hi], self.val[lo:hi], (r1 - r0, self.shape[1]), self.device,
+                         self.chunk_nnz, ids)
+
     def workspace(self, f):
         ws = self._ws.get(f)
         if ws is None:

@@ -16,6 +16,10 @@ class HostCSR:
         self.shape = (int(shape[0]), int(shape[1]))
         self.nnz = int(self.indices.shape[0])
 
+    def row_range(self, r0, r1):
+        p = self.indptr
+        return HostCSR(p[r0:r1 + 1] - p[r0], self.indices[p[r0]:p[r1]], self.data[p[r0]:p[r1]], (r1 - r0, self.shape[1]))
+
 
 class GramCache:
     def __init__(self, f, lamb, device):
