@@ -35,10 +35,12 @@ extern "C" {
 #define ALS_ERR_WORKSPACE 3   /* workspace smaller than the matching *_workspace_bytes()  */
 #define ALS_ERR_HIP 4         /* a HIP runtime call failed (message holds hipGetErrorString) */
 
-#define ALS_MAX_FACTORS 128         /* largest f the exact-solve path supports                 */
+#define ALS_MAX_FACTORS 256         /* largest f (Gram, conjugate-gradient half-sweep, scoring) */
+#define ALS_MAX_FACTORS_EXACT 128   /* largest f of the exact (Cholesky) half-sweep            */
 #define ALS_DEFAULT_CHUNK_NNZ 2048  /* rows longer than this are split (multiple of 64)        */
 #define ALS_GRAM_CHUNK_ROWS 1024    /* rows per first-level Gram partial                       */
 #define ALS_GRAM_SUPER_ROWS 65536   /* rows per second-level Gram partial (64 chunks)          */
+#define ALS_GRAM_WIDE_CHUNK_ROWS 4096 /* rows per first-level partial when f > ALS_MAX_FACTORS_EXACT */
 
 /* Description of the last error on this thread ("" if none).  Replaces the Python
  * exceptions / asserts of the reference (reclibwh/core/ALS.py:124,145). */
@@ -87,6 +89,9 @@ int32_t als_plan_fill(const int64_t *rowptr_host, int64_t n_rows, int32_t chunk_
  * The sum over rows is a fixed three-level tree (1024-row chunks, 64-chunk groups, then
  * the groups in order), so a Gram assembled from als_gram_partials_f32 calls on several
  * devices equals the single-device one bit for bit.
+ * f > ALS_MAX_FACTORS_EXACT: the same tree over 4096-row chunks of 64 x 64 blocks; tiles_out
+ * then holds the summed partial (no lamb; only the conjugate-gradient half-sweep exists for
+ * such f and it takes gram_out and lamb).
  * ------------------------------------------------------------------------------------ */
 size_t als_gram_tiles_bytes(int32_t f);
 size_t als_gram_workspace_bytes(int64_t n, int32_t f);
@@ -134,6 +139,28 @@ int32_t als_half_sweep_csr_f32(const int64_t *rowptr, const int32_t *col, const 
                                const float *gram_tiles, int32_t f, float alpha, float *Xown, int64_t ldx,
                                double *absdiff_out, int32_t *info_out, void *workspace, size_t ws_bytes,
                                void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Conjugate-gradient half-sweep, 1 <= f <= ALS_MAX_FACTORS.  Same normal equations and same
+ * in-place update of Xown as als_half_sweep_csr_f32, but each row's system is advanced by
+ * exactly `cg_steps` conjugate-gradient steps from the row's current value instead of being
+ * solved (A_u is never formed: A_u v = gram v + sum_j alpha r_uj (y_j . v) y_j + lamb v).
+ * No counterpart in the reference, which inverts A_u (reclibwh/core/ALS.py:82,172); it is the
+ * solver for factor counts whose f x f system no longer fits one wavefront's registers.
+ * With cg_steps >= f it reproduces the exact solve to rounding.  A row without entries gets 0.
+ *
+ * gram     [device] f*f floats, row major: gram_out of als_gram_f32 for Yopp (no lamb).
+ * info_out [device] incremented once per (row, step) with p^T A p <= 0 (not positive definite).
+ * Other arguments as for als_half_sweep_csr_f32.
+ * ------------------------------------------------------------------------------------ */
+size_t als_half_sweep_cg_workspace_bytes(int64_t n_rows, int64_t n_slots, int32_t f);
+int32_t als_half_sweep_cg_f32(const int64_t *rowptr, const int32_t *col, const float *val, int64_t n_rows,
+                              const int64_t *row_ids, const als_item_t *items, int64_t n_items,
+                              const als_long_row_t *long_rows, int64_t n_long, int64_t n_slots,
+                              int32_t chunk_nnz, const float *Yopp, int64_t n_opp, int64_t ldy, const float *gram,
+                              float lamb, int32_t f, float alpha, int32_t cg_steps, float *Xown, int64_t ldx,
+                              double *absdiff_out, int32_t *info_out, void *workspace, size_t ws_bytes,
+                              void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Scoring - replaces ALSTrainer.predict + SimpleMFRecAlgo.recommend

@@ -16,6 +16,11 @@ reference repository root):
   init_factors              reclibwh/core/ALS.py:56-65 ("ref") and :248-260 ("tf")
   padded_batch              reclibwh/utils/utils.py:142-173 + data/PresetIterators.py:11-17
   half_sweep_batched_f32    reclibwh/core/ALS.py:160-199 + :201-233 (TF path, float32)
+  half_sweep_cg             the same normal equations as ALS.py:82-86, solved by a fixed number of
+                            conjugate-gradient steps (Hestenes-Stiefel; warm start from the current
+                            row) instead of inv().  The reference has no CG: this restates the
+                            published algorithm and is pinned to the golden vectors through its
+                            limit - with enough steps it must reproduce half_sweep_exact.
   recommend_full            reclibwh/core/RecAlgos.py:20-32
   cosine_similar            reclibwh/core/RecAlgos.py:38-73
   compute_ap / compute_auc  reclibwh/utils/eval_utils.py:5-37
@@ -79,6 +84,49 @@ def half_sweep_exact(indptr, indices, data, Yfix, Xold, lamb, alpha, rows=None):
         L = np.linalg.inv(Y2 + np.matmul(Yp.T, alpha * np.multiply(np.expand_dims(rp, axis=1), Yp)) + Lamb)
         cup = 1 + alpha * rp
         Xp[u, :] = np.matmul(L, np.tensordot(Yp.T, cup, axes=1))
+    return Xp
+
+
+def half_sweep_cg(indptr, indices, data, Yfix, Xold, lamb, alpha, steps, rows=None, dtype=np.float64):
+    """Per row u, `steps` conjugate-gradient steps on A x = b, started at x = Xold[u], with
+        A = Y2 + Yp^T diag(alpha rp) Yp + lamb I,  b = Yp^T (1 + alpha rp)      (ALS.py:82-86)
+    A is never formed: A v = Y2 v + Yp^T (alpha rp * (Yp v)) + lamb v.
+
+        r = b - A x;  p = r;  rs = r.r
+        repeat steps times:  Ap = A p;  a = rs / p.Ap;  x += a p;  r -= a Ap
+                             rs' = r.r;  p = r + (rs'/rs) p;  rs = rs'
+    A step with rs == 0 or p.Ap <= 0 changes nothing.  A row without stored entries has the
+    exact solution 0 and gets it.  Stored zeros are dropped (ALS.py:79)."""
+    Yfix = np.asarray(Yfix, dtype=dtype)
+    Xp = np.array(Xold, dtype=dtype, copy=True)
+    Y2 = gram(Yfix).astype(dtype)
+    lamb = dtype(lamb); alpha = dtype(alpha)
+    it = range(Xp.shape[0]) if rows is None else rows
+    for u in it:
+        s, e = int(indptr[u]), int(indptr[u + 1])
+        cols = np.asarray(indices[s:e]); rp = np.asarray(data[s:e], dtype=dtype)
+        keep = rp != 0
+        cols, rp = cols[keep], rp[keep]
+        if len(cols) == 0:
+            Xp[u] = 0
+            continue
+        Yp = Yfix[cols]; w = alpha * rp
+
+        def A(v):
+            return Y2 @ v + Yp.T @ (w * (Yp @ v)) + lamb * v
+
+        x = Xp[u].copy()
+        r = Yp.T @ (1 + w) - A(x)
+        p = r.copy(); rs = r @ r
+        for _ in range(steps):
+            Ap = A(p); pAp = p @ Ap
+            if not (rs > 0 and pAp > 0):
+                break
+            a = rs / pAp
+            x = x + a * p; r = r - a * Ap
+            rs_new = r @ r
+            p = r + (rs_new / rs) * p; rs = rs_new
+        Xp[u] = x
     return Xp
 
 

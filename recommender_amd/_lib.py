@@ -19,7 +19,9 @@ ERROR_NAMES = {1: "invalid argument", 2: "unsupported", 3: "workspace too small"
 DEFAULT_CHUNK_NNZ = 2048
 GRAM_CHUNK_ROWS = 1024
 GRAM_SUPER_ROWS = 65536
-MAX_FACTORS = 128
+MAX_FACTORS = 256
+MAX_FACTORS_EXACT = 128
+GRAM_WIDE_CHUNK_ROWS = 4096
 
 c_i32, c_i64, c_f32, c_sz, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
 
@@ -40,6 +42,10 @@ SIGNATURES = {
     "als_predict_pairs_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),
     "als_normalize_rows_f32": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_vp]),
     "als_half_sweep_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32]),
+    "als_half_sweep_cg_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32]),
+    "als_half_sweep_cg_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32,
+                                      c_vp, c_i64, c_i64, c_vp, c_f32, c_i32, c_f32, c_i32, c_vp, c_i64, c_vp, c_vp,
+                                      c_vp, c_sz, c_vp]),
     "als_half_sweep_csr_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32,
                                        c_vp, c_i64, c_i64, c_vp, c_i32, c_f32, c_vp, c_i64, c_vp, c_vp, c_vp, c_sz,
                                        c_vp]),

@@ -77,10 +77,13 @@ def als_update_cache(Y, lamb, cache=None, group=None, backend=ops):
     return backend.gram_finalize(torch.cat(parts, 0).to(Y.device).contiguous(), f, lamb, out=cache)
 
 
-def run_als_epoch(csr, X, Y, cache, alpha, absdiff=None, info=None, backend=ops):
+def run_als_epoch(csr, X, Y, cache, alpha, absdiff=None, info=None, backend=ops, cg_steps=0):
     """One half-sweep over the rows of `csr`: re-solves those rows of X in place against the
     fixed Y and its cache (ALS.py:201-233).  Returns the device scalar sum|X_old - X_new|
-    (float64); the reference's return value is that divided by n_rows * f."""
+    (float64); the reference's return value is that divided by n_rows * f.
+    cg_steps > 0: that many conjugate-gradient steps per row instead of the exact solve."""
+    if cg_steps:
+        return backend.half_sweep_cg(csr, Y, cache, X, alpha, cg_steps, absdiff=absdiff, info=info)
     return backend.half_sweep(csr, Y, cache, X, alpha, absdiff=absdiff, info=info)
 
 
@@ -141,7 +144,7 @@ class ALSEngine:
     """
 
     def __init__(self, csr_users, csr_items, X, Y, lamb, alpha, user_bounds=None, item_bounds=None, group=None,
-                 backend=ops, overlap_chunks=None):
+                 backend=ops, overlap_chunks=None, solver="auto", cg_steps=3):
         self.group = group
         self.backend = backend      # the HIP operators; tests inject a CPU stand-in to exercise the sharding logic
         self.world = torch.distributed.get_world_size(group) if group is not None else 1
@@ -161,6 +164,18 @@ class ALSEngine:
         self.n_users, self.n_items = self.user_bounds[-1], self.item_bounds[-1]
         if X.shape[0] < self.n_users or Y.shape[0] < self.n_items:
             raise ValueError("factor matrices are smaller than the rating matrix")
+        # "cholesky": exact solve (f <= 128).  "cg": cg_steps conjugate-gradient steps per row and
+        # half-sweep, warm-started (any f <= 256).  "auto": exact where it exists.
+        if solver not in ("auto", "cholesky", "cg"):
+            raise ValueError("solver must be 'auto', 'cholesky' or 'cg'")
+        if solver == "auto":
+            solver = "cholesky" if self.f <= _lib.MAX_FACTORS_EXACT else "cg"
+        if solver == "cholesky" and self.f > _lib.MAX_FACTORS_EXACT:
+            raise ValueError("the exact solve supports f <= %d; use solver='cg'" % _lib.MAX_FACTORS_EXACT)
+        self.solver = solver
+        self.cg_steps = int(cg_steps) if solver == "cg" else 0
+        if solver == "cg" and self.cg_steps < 1:
+            raise ValueError("cg_steps must be >= 1")
         self.cache_Y = backend.GramCache(self.f, lamb, X.device)
         self.cache_X = backend.GramCache(self.f, lamb, X.device)
         self._dX = torch.zeros(1, dtype=torch.float64, device=X.device)
@@ -205,7 +220,7 @@ class ALSEngine:
             if csr is not None:
                 if self.pre_sweep_hook: self.pre_sweep_hook("users")
                 run_als_epoch(csr, self.X[u0 + r0:u0 + r1], self.Y, self.cache_Y, self.alpha, dbuf, self.info,
-                              self.backend)
+                              self.backend, self.cg_steps)
             else:
                 dbuf.zero_()
             if not chunked:
@@ -238,7 +253,7 @@ class ALSEngine:
         if i1 > i0:
             if self.pre_sweep_hook: self.pre_sweep_hook("items")
             run_als_epoch(self.csr_items, self.Y[i0:i1], self.X, self.cache_X, self.alpha, self._dY, self.info,
-                          self.backend)
+                          self.backend, self.cg_steps)
         if self.world > 1:
             _all_gather_rows(self.Y[: self.n_items], self.item_bounds, self.rank, self.group)
 

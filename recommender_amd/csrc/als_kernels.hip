@@ -31,6 +31,15 @@
 
 #include "als_hip.h"
 
+int32_t als_sum_rowdiff_(const float *rowdiff, int64_t n_rows, double *partials, double *out, hipStream_t st);
+// wide Gram (128 < f <= 256), als_cg.hip
+size_t als_gram_wide_tiles_bytes_(int f);
+size_t als_gram_wide_workspace_bytes_(int64_t n, int f);
+int32_t als_gram_wide_partials_(const float *Y, int64_t row_begin, int64_t row_end, int32_t f, int64_t ldy,
+                                float *super_out, void *workspace, hipStream_t st);
+int32_t als_gram_wide_finalize_(const float *super_in, int64_t n_super, int32_t f, float *gram_out, float *tiles_out,
+                                hipStream_t st);
+
 namespace {
 
 // ----------------------------------------------------------------------------- errors
@@ -721,19 +730,22 @@ static int32_t half_sweep_impl(const SweepParams &p, int64_t n_rows, int64_t n_i
         hipLaunchKernelGGL(sweep_long_rows_kernel<VW>, dim3((unsigned)n_long), dim3(64), 0, st, p);
         ALS_HIP_CHECK(hipGetLastError());
     }
-    if (absdiff_out) {
-        const int64_t nb = ceil_div(n_rows, DIFF_BLOCK_ROWS);
-        hipLaunchKernelGGL(sum_to_double_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, p.rowdiff, n_rows,
-                           DIFF_BLOCK_ROWS, diff_partials);
-        ALS_HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(sum_to_double_kernel<double>, dim3(1), dim3(256), 0, st, diff_partials, nb, (int)nb,
-                           absdiff_out);
-        ALS_HIP_CHECK(hipGetLastError());
-    }
+    if (absdiff_out) return als_sum_rowdiff_(p.rowdiff, n_rows, diff_partials, absdiff_out, st);
     return ALS_OK;
 }
 
 }  // namespace
+
+// shared with als_cg.hip: *out = sum of rowdiff[0 .. n_rows) in double, fixed two-level order
+int32_t als_sum_rowdiff_(const float *rowdiff, int64_t n_rows, double *partials, double *out, hipStream_t st) {
+    const int64_t nb = ceil_div(n_rows, DIFF_BLOCK_ROWS);
+    hipLaunchKernelGGL(sum_to_double_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, rowdiff, n_rows,
+                       DIFF_BLOCK_ROWS, partials);
+    ALS_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(sum_to_double_kernel<double>, dim3(1), dim3(256), 0, st, partials, nb, (int)nb, out);
+    ALS_HIP_CHECK(hipGetLastError());
+    return ALS_OK;
+}
 
 // shared with als_scoring.hip: records the calling thread's last error and returns `code`
 int als_fail_(int code, const char *fmt, ...) {
@@ -815,11 +827,13 @@ int32_t als_plan_fill(const int64_t *rowptr, int64_t n_rows, int32_t chunk_nnz, 
 // ----------------------------------------------------------------------------- gram
 size_t als_gram_tiles_bytes(int32_t f) {
     if (f < 1 || f > ALS_MAX_FACTORS) return 0;
+    if (f > ALS_MAX_FACTORS_EXACT) return als_gram_wide_tiles_bytes_(f);
     return (size_t)tq_for(f) * 64 * sizeof(float);
 }
 
 size_t als_gram_workspace_bytes(int64_t n, int32_t f) {
     if (f < 1 || f > ALS_MAX_FACTORS || n < 0) return 0;
+    if (f > ALS_MAX_FACTORS_EXACT) return als_gram_wide_workspace_bytes_(n, f);
     const size_t tile = als_gram_tiles_bytes(f);
     const int64_t n_chunks = std::max<int64_t>(1, ceil_div(n, ALS_GRAM_CHUNK_ROWS));
     const int64_t n_super = std::max<int64_t>(1, ceil_div(n, ALS_GRAM_SUPER_ROWS));
@@ -839,6 +853,7 @@ int32_t als_gram_partials_f32(const float *Y, int64_t row_begin, int64_t row_end
         return fail(ALS_ERR_WORKSPACE, "gram workspace too small: %zu < %zu", ws_bytes,
                     als_gram_workspace_bytes(row_end - row_begin, f));
     hipStream_t st = (hipStream_t)stream;
+    if (f > ALS_MAX_FACTORS_EXACT) return als_gram_wide_partials_(Y, row_begin, row_end, f, ldy, super_out, workspace, st);
     switch (vw_for(f)) {
         case 1: return gram_partials_impl<1>(Y, row_begin, row_end, f, ldy, super_out, workspace, st);
         case 2: return gram_partials_impl<2>(Y, row_begin, row_end, f, ldy, super_out, workspace, st);
@@ -853,6 +868,7 @@ int32_t als_gram_finalize_f32(const float *super_in, int64_t n_super, int32_t f,
         return fail(ALS_ERR_INVALID_ARG, "als_gram_finalize_f32: null pointer or n_super < 1");
     if (f < 1 || f > ALS_MAX_FACTORS) return fail(ALS_ERR_UNSUPPORTED, "f=%d outside [1, %d]", f, ALS_MAX_FACTORS);
     hipStream_t st = (hipStream_t)stream;
+    if (f > ALS_MAX_FACTORS_EXACT) return als_gram_wide_finalize_(super_in, n_super, f, gram_out, tiles_out, st);
     const int elems = tq_for(f) * 64;
     const dim3 grid((elems + 255) / 256), block(256);
     switch (vw_for(f)) {
@@ -871,7 +887,7 @@ int32_t als_gram_f32(const float *Y, int64_t n, int32_t f, int64_t ldy, float la
     if (!workspace || ws_bytes < als_gram_workspace_bytes(n, f) || als_gram_workspace_bytes(n, f) == 0)
         return fail(ALS_ERR_WORKSPACE, "gram workspace too small or f unsupported");
     const size_t tile = als_gram_tiles_bytes(f);
-    const int64_t n_chunks = ceil_div(n, ALS_GRAM_CHUNK_ROWS);
+    const int64_t n_chunks = ceil_div(n, f > ALS_MAX_FACTORS_EXACT ? ALS_GRAM_WIDE_CHUNK_ROWS : ALS_GRAM_CHUNK_ROWS);
     const int64_t n_super = ceil_div(n, ALS_GRAM_SUPER_ROWS);
     float *super = (float *)((char *)workspace + (size_t)n_chunks * tile);
     int32_t rc = als_gram_partials_f32(Y, 0, n, f, ldy, super, workspace, ws_bytes, stream);
@@ -881,7 +897,7 @@ int32_t als_gram_f32(const float *Y, int64_t n, int32_t f, int64_t ldy, float la
 
 // ----------------------------------------------------------------------------- half sweep
 size_t als_half_sweep_workspace_bytes(int64_t n_rows, int64_t n_slots, int32_t f) {
-    if (f < 1 || f > ALS_MAX_FACTORS || n_rows < 0 || n_slots < 0) return 0;
+    if (f < 1 || f > ALS_MAX_FACTORS_EXACT || n_rows < 0 || n_slots < 0) return 0;
     const int vw = vw_for(f);
     const size_t pq = (size_t)(vw * (vw + 1) / 2 * 4 + vw) * 64 * sizeof(float);
     size_t b = align_up((size_t)n_slots * pq, 256);
@@ -905,7 +921,9 @@ int32_t als_half_sweep_csr_f32(const int64_t *rowptr, const int32_t *col, const 
         return fail(ALS_ERR_INVALID_ARG, "plan sizes are inconsistent (n_items=%lld n_long=%lld n_slots=%lld)",
                     (long long)n_items, (long long)n_long, (long long)n_slots);
     if (chunk_nnz < 64 || chunk_nnz % 64) return fail(ALS_ERR_INVALID_ARG, "chunk_nnz must be a positive multiple of 64");
-    if (f < 1 || f > ALS_MAX_FACTORS) return fail(ALS_ERR_UNSUPPORTED, "f=%d outside [1, %d]", f, ALS_MAX_FACTORS);
+    if (f < 1 || f > ALS_MAX_FACTORS_EXACT)
+        return fail(ALS_ERR_UNSUPPORTED, "f=%d outside [1, %d] (the exact solve; als_half_sweep_cg_f32 goes to %d)", f,
+                    ALS_MAX_FACTORS_EXACT, ALS_MAX_FACTORS);
     if (ldy < f || ldx < f) return fail(ALS_ERR_INVALID_ARG, "leading dimension smaller than f");
     if (n_items > 0x7fffffffLL) return fail(ALS_ERR_UNSUPPORTED, "too many work items for one launch");
     if (ws_bytes < als_half_sweep_workspace_bytes(n_rows, n_slots, f))

@@ -5,6 +5,8 @@
   gram           als_update_cache        (reclibwh/core/ALS.py:235-246)
   half_sweep     run_als_epoch / run_als_step / als_run_regression
                                           (reclibwh/core/ALS.py:160-233)
+  half_sweep_cg  the same half-sweep with a fixed number of conjugate-gradient steps per row
+                 instead of the exact solve (no reference counterpart; the path for f > 128)
 
 torch is used for device memory and streams only; every computation is a HIP kernel
 in libals_hip.so.  Arguments are validated here (dtype, contiguity, device, index
@@ -129,6 +131,16 @@ class DeviceCSR:
         return DeviceCSR(ptr - lo, self.col[lo:hi], self.val[lo:hi], (r1 - r0, self.shape[1]), self.device,
                          self.chunk_nnz, ids)
 
+    def workspace_cg(self, f):
+        ws = self._ws.get(("cg", f))
+        if ws is None:
+            nbytes = lib.als_half_sweep_cg_workspace_bytes(self.shape[0], self.n_slots, f)
+            if nbytes == 0:
+                raise ValueError("unsupported factor count f=%d" % f)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws[("cg", f)] = ws
+        return ws
+
     def workspace(self, f):
         ws = self._ws.get(f)
         if ws is None:
@@ -236,6 +248,40 @@ def half_sweep(csr, Yopp, gram_cache, Xown, alpha, absdiff=None, info=None):
             csr.n_items, _ptr(csr.long_rows), csr.n_long, csr.n_slots, csr.chunk_nnz, _ptr(Yopp), csr.shape[1], ldy,
             _ptr(gram_cache.tiles), f, float(alpha), _ptr(Xown), ldx, _ptr(absdiff), _ptr(info), _ptr(ws),
             ws.numel(), _stream()), "als_half_sweep_csr_f32")
+    return absdiff
+
+
+def half_sweep_cg(csr, Yopp, gram_cache, Xown, alpha, cg_steps, absdiff=None, info=None):
+    """One half-sweep by `cg_steps` conjugate-gradient steps per row, warm-started at the current
+    rows of Xown (updated in place).  Same contract as half_sweep otherwise; 1 <= f <= 256."""
+    if not isinstance(csr, DeviceCSR):
+        raise ValueError("csr must be a DeviceCSR")
+    ldy = _factor_ld(Yopp, "Yopp")
+    ldx = _factor_ld(Xown, "Xown")
+    f = Yopp.shape[1]
+    if Xown.shape[1] != f or gram_cache.f != f:
+        raise ValueError("factor counts differ: Yopp %d, Xown %d, gram %d" % (f, Xown.shape[1], gram_cache.f))
+    if Yopp.shape[0] < csr.shape[1]:
+        raise ValueError("Yopp has %d rows but the CSR has %d columns" % (Yopp.shape[0], csr.shape[1]))
+    need_rows = (csr.row_ids_max + 1) if csr.row_ids is not None else csr.shape[0]
+    if Xown.shape[0] < need_rows:
+        raise ValueError("Xown has %d rows, the CSR updates row %d" % (Xown.shape[0], need_rows - 1))
+    if Yopp.device != csr.device or Xown.device != csr.device:
+        raise ValueError("tensors live on different devices")
+    if Xown.data_ptr() == Yopp.data_ptr():
+        raise ValueError("Xown and Yopp must not alias")
+    cg_steps = int(cg_steps)
+    if not (1 <= cg_steps <= 1024):
+        raise ValueError("cg_steps must be in [1, 1024]")
+    if absdiff is None:
+        absdiff = torch.zeros(1, dtype=torch.float64, device=csr.device)
+    ws = csr.workspace_cg(f)
+    with torch.cuda.device(csr.device):
+        check(lib.als_half_sweep_cg_f32(
+            _ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.val), csr.shape[0], _ptr(csr.row_ids), _ptr(csr.items),
+            csr.n_items, _ptr(csr.long_rows), csr.n_long, csr.n_slots, csr.chunk_nnz, _ptr(Yopp), csr.shape[1], ldy,
+            _ptr(gram_cache.gram), float(gram_cache.lamb), f, float(alpha), cg_steps, _ptr(Xown), ldx, _ptr(absdiff),
+            _ptr(info), _ptr(ws), ws.numel(), _stream()), "als_half_sweep_cg_f32")
     return absdiff
 
 

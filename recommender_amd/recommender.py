@@ -30,6 +30,8 @@ DEFAULTS = dict(f=20,           # ALS.json.template:26 (the reference's layer wi
                 phantom_rows=0,     # >0: TensorFlow-path layout, layers get extra never-updated rows
                                     # that still enter the Gram (ALS.py:243, ALS.py:456)
                 chunk_nnz=2048,
+                solver="auto",      # "cholesky" (exact, f <= 128), "cg", or "auto" = exact where it exists
+                cg_steps=3,         # conjugate-gradient steps per row and half-sweep when solver is "cg"
                 med_score=3.0,      # ALS.py:402
                 eval_lim=200)       # EvalProto.py:22
 
@@ -111,7 +113,8 @@ class RecommenderALS:
         Ut = sps.csr_matrix(self.Utrain.T); Ut.sort_indices()
         cu = ops.DeviceCSR.from_scipy(self.Utrain, self.device, c["chunk_nnz"])
         ci = ops.DeviceCSR.from_scipy(Ut, self.device, c["chunk_nnz"])
-        self.engine = ALSEngine(cu, ci, self.X, self.Y, c["lamb"], c["alpha"])
+        self.engine = ALSEngine(cu, ci, self.X, self.Y, c["lamb"], c["alpha"], solver=c["solver"],
+                                cg_steps=c["cg_steps"])
 
     # ------------------------------------------------------------------ training
     def train(self, epochs=None, evaluate=None):
@@ -227,7 +230,12 @@ class RecommenderALS:
         csr = ops.DeviceCSR.from_scipy(U, self.device, self.config["chunk_nnz"], row_ids=uniq)
         cache = ops.gram(self.Y, self.config["lamb"])
         info = torch.zeros(1, dtype=torch.int32, device=self.device)
-        ops.half_sweep(csr, self.Y, cache, self.X, self.config["alpha"], info=info)
+        f = self.X.shape[1]
+        if self.config["solver"] == "cg" or f > 128:
+            # a brand-new row starts far from its solution: f steps reach it to rounding
+            ops.half_sweep_cg(csr, self.Y, cache, self.X, self.config["alpha"], max(f, self.config["cg_steps"]), info=info)
+        else:
+            ops.half_sweep(csr, self.Y, cache, self.X, self.config["alpha"], info=info)
         if int(info.item()):
             raise FloatingPointError("fold-in system not positive definite in float32")
 

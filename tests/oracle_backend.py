@@ -62,3 +62,15 @@ def half_sweep(csr, Yopp, cache, Xown, alpha, absdiff=None, info=None):
         absdiff = torch.zeros(1, dtype=torch.float64)
     absdiff[0] = float(np.abs(old - new).sum())
     return absdiff
+
+
+def half_sweep_cg(csr, Yopp, cache, Xown, alpha, cg_steps, absdiff=None, info=None):
+    from oracle import als_ref
+    old = Xown.numpy().astype(np.float64)
+    new = als_ref.half_sweep_cg(csr.indptr, csr.indices, csr.data, Yopp.numpy().astype(np.float64), old, cache.lamb,
+                                alpha, cg_steps)
+    Xown.copy_(torch.from_numpy(new).to(Xown.dtype))
+    if absdiff is None:
+        absdiff = torch.zeros(1, dtype=torch.float64)
+    absdiff[0] = float(np.abs(old - new).sum())
+    return absdiff

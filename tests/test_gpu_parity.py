@@ -193,4 +193,7 @@ def test_invalid_arguments_raise(ra):
     with pytest.raises(ValueError):
         ra.half_sweep(csr, Y[:4], gc, X, 1.0)                              # too few opposite rows
     with pytest.raises(ValueError):
-        ra.gram(_dev(rng.normal(size=(4, 200))), 0.1)                      # f beyond the supported range
+        ra.gram(_dev(rng.normal(size=(4, 300))), 0.1)                      # f beyond the supported range
+    with pytest.raises(ValueError):
+        ra.half_sweep(ra.DeviceCSR(ptr, ind, dat, (2, 6), "cuda"), _dev(rng.normal(size=(6, 200))), ra.gram(_dev(rng.normal(size=(6, 200))), 0.1),
+                      _dev(rng.normal(size=(2, 200))), 1.0)                   # exact solve ends at f = 128

@@ -101,3 +101,29 @@ def test_batched_f32_matches_exact_at_reference_test_settings(golden):
                                              float(g["alpha"]), batchsize=shape[0])
     assert np.allclose(X, g["Xnew"], rtol=1e-4, atol=1e-5)
     assert diff == pytest.approx(np.mean(np.abs(g["Xinit"] - g["Xnew"])), rel=1e-4)
+
+
+@pytest.mark.parametrize("K", [8, 20, 32])
+def test_cg_oracle_pinned_through_its_limit(golden, K):
+    """half_sweep_cg restates a published algorithm the reference does not contain; what pins it
+    to the reference is that, run to convergence, it must land on ALSRef's exact half-sweep
+    (golden vectors), and that fewer steps move monotonically towards it."""
+    g = golden("g2_powerlaw_train.npz")
+    ptr, ind, dat, shape = _csr(g)
+    tag = "K%d_ref" % K
+    X0, Y0, X1 = g[tag + "_X0"], g[tag + "_Y0"], g[tag + "_X1"]
+    errs = []
+    for steps in (1, 3, K, 3 * K):
+        X = als_ref.half_sweep_cg(ptr, ind, dat, Y0, X0, float(g["lamb"]), float(g["alpha"]), steps)
+        errs.append(np.abs(X - X1).max() / np.abs(X1).max())
+    assert errs[-1] < 1e-9
+    assert errs[0] > errs[1] > errs[2] >= errs[3]
+
+
+def test_cg_oracle_edge_cases(golden):
+    g = golden("g3_edge_cases.npz")
+    ptr, ind, dat, shape = _csr(g)
+    K = g["Y0"].shape[1]
+    X = als_ref.half_sweep_cg(ptr, ind, dat, g["Y0"], g["X0"], 0.01, 40.0, 4 * K)
+    np.testing.assert_allclose(X, g["Xnew"], rtol=1e-7, atol=1e-9)
+    assert np.all(X[0] == 0) and np.all(X[-1] == 0)          # rows without entries: exactly 0
