@@ -33,6 +33,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2_ml25m_syn")
     ap.add_argument("--factors", type=int, default=None)
+    ap.add_argument("--solver", default="cholesky", choices=["cholesky", "cg"],
+                    help="cholesky: exact solve (f <= 128, the default workload); cg: fixed-step conjugate gradient")
+    ap.add_argument("--cg-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work per half-sweep sample")
     return ap.parse_args()
@@ -146,7 +149,9 @@ def main():
     Y = torch.from_numpy(Yh.astype(np.float32)).to(dev)
     csr_u = ops.DeviceCSR(U[0], U[1], U[2], (ub[rank + 1] - ub[rank], M), dev)
     csr_i = ops.DeviceCSR(Ut[0], Ut[1], Ut[2], (ib[rank + 1] - ib[rank], N), dev)
-    eng = ALSEngine(csr_u, csr_i, X, Y, wl["lamb"], wl["alpha"], ub, ib, group)
+    eng = ALSEngine(csr_u, csr_i, X, Y, wl["lamb"], wl["alpha"], ub, ib, group, solver=args.solver,
+                    cg_steps=args.cg_steps)
+    cg = args.solver == "cg"
 
     def sync():
         torch.cuda.synchronize()
@@ -167,9 +172,17 @@ def main():
 
     def tap(which):
         e0, e1 = pool.pop(), pool.pop()
-        lib.als_profile_tap_next_sweep(ctypes.c_void_p(e0.cuda_event), ctypes.c_void_p(e1.cuda_event))
+        if cg:      # several kernels per half-sweep: events around the whole call, on the launch stream
+            e0.record()
+        else:       # exact path: the library records the events around the one gather/accumulate/solve kernel
+            lib.als_profile_tap_next_sweep(ctypes.c_void_p(e0.cuda_event), ctypes.c_void_p(e1.cuda_event))
         taps[which].append((e0, e1))
 
+    def tap_end(which):
+        if cg:
+            taps[which][-1][1].record()
+
+    eng.post_sweep_hook = tap_end
     eng.pre_sweep_hook = tap
     sync()
     t0 = time.perf_counter()
@@ -177,7 +190,7 @@ def main():
         eng.step()
     sync()
     dt = time.perf_counter() - t0
-    eng.pre_sweep_hook = None
+    eng.pre_sweep_hook = eng.post_sweep_hook = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -189,14 +202,22 @@ def main():
     # nnz*(4 col + 4 val + 4f gathered row) + n_rows*(8 rowptr + 4f written row)
     ku = sum(e0.elapsed_time(e1) for e0, e1 in taps["users"]) / args.steps
     ki = sum(e0.elapsed_time(e1) for e0, e1 in taps["items"]) / args.steps
-    bytes_u = csr_u.nnz * (8 + 4 * f) + csr_u.shape[0] * (8 + 4 * f)
-    bytes_i = csr_i.nnz * (8 + 4 * f) + csr_i.shape[0] * (8 + 4 * f)
+    if cg:
+        # per half-sweep: cg_steps+1 gather passes over the entries, plus the per-row vectors each pass
+        # reads and writes (x, r, p, z and the GEMM's operand and result): see DESIGN.md
+        sp = args.cg_steps
+        row_vecs = 4 + 7 * (sp - 1) + 6 + 2 * (sp + 1)
+        bytes_u = (sp + 1) * csr_u.nnz * (8 + 4 * f) + csr_u.shape[0] * (8 + 4 * f * row_vecs)
+        bytes_i = (sp + 1) * csr_i.nnz * (8 + 4 * f) + csr_i.shape[0] * (8 + 4 * f * row_vecs)
+    else:
+        bytes_u = csr_u.nnz * (8 + 4 * f) + csr_u.shape[0] * (8 + 4 * f)
+        bytes_i = csr_i.nnz * (8 + 4 * f) + csr_i.shape[0] * (8 + 4 * f)
     achieved = (bytes_u + bytes_i) / ((ku + ki) * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(args.workload + "_f%d" % f, {}).get("hbm_bytes_per_launch")
+            traffic = json.load(open(tpath)).get(args.workload + "_f%d" % f + ("_cg" if cg else ""), {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
@@ -206,10 +227,12 @@ def main():
             "value": 2.0 * nnz * args.steps / dt, "unit": "nnz/s", "iters_per_s": args.steps / dt,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %d users x %d items, %d nnz, f=%d, lamb=%g, alpha=%g, exact Cholesky solve"
-                                   % (args.workload, N, M, nnz, f, wl["lamb"], wl["alpha"]),
+            "config": {"workload": "%s: %d users x %d items, %d nnz, f=%d, lamb=%g, alpha=%g, %s"
+                                   % (args.workload, N, M, nnz, f, wl["lamb"], wl["alpha"],
+                                      "%d conjugate-gradient steps per row" % args.cg_steps if cg else "exact Cholesky solve"),
                        "parallelism": "dp%d (user/item row shards, all-gather of factors)" % world},
-            "roofline": {"bound": "hbm", "kernel": "sweep_items_kernel (per-row gather/accumulate + solve)",
+            "roofline": {"bound": "hbm", "kernel": "cg half-sweep (cg_items_kernel passes + Gram GEMM)" if cg
+                         else "sweep_items_kernel (per-row gather/accumulate + solve)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_ms": (ku + ki) / 2,
                          "launch_ms": {"user_sweep": ku, "item_sweep": ki},

@@ -183,6 +183,7 @@ class ALSEngine:
         self.info = torch.zeros(1, dtype=torch.int32, device=X.device)
         self.trace = []
         self.pre_sweep_hook = None     # callable("users" | "items"), run just before each sweep launch
+        self.post_sweep_hook = None    # the same, just after it
         # Multi-GPU: the user sweep runs as `overlap_chunks` row chunks; the all-gather of chunk c
         # runs on a side stream beside the sweep of chunk c+1, so only the last chunk's exchange is
         # exposed.  A row's result does not depend on which launch computes it, so factors are
@@ -221,6 +222,7 @@ class ALSEngine:
                 if self.pre_sweep_hook: self.pre_sweep_hook("users")
                 run_als_epoch(csr, self.X[u0 + r0:u0 + r1], self.Y, self.cache_Y, self.alpha, dbuf, self.info,
                               self.backend, self.cg_steps)
+                if self.post_sweep_hook: self.post_sweep_hook("users")
             else:
                 dbuf.zero_()
             if not chunked:
@@ -254,6 +256,7 @@ class ALSEngine:
             if self.pre_sweep_hook: self.pre_sweep_hook("items")
             run_als_epoch(self.csr_items, self.Y[i0:i1], self.X, self.cache_X, self.alpha, self._dY, self.info,
                           self.backend, self.cg_steps)
+            if self.post_sweep_hook: self.post_sweep_hook("items")
         if self.world > 1:
             _all_gather_rows(self.Y[: self.n_items], self.item_bounds, self.rank, self.group)
 

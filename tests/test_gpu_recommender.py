@@ -174,3 +174,54 @@ def test_evaluate_matches_oracle_map(ra):
     oscore = als_ref.map_at_k(oidx, (te.indptr, te.indices, te.data), (tr.indptr, tr.indices, tr.data), users, 3.0, 200)
     assert abs(score - oscore) < 5e-4 and score > 0.9, (score, oscore)
     assert len(rec.eval_scores) == 3
+
+
+def test_c1_full_training_metrics_to_three_decimals(ra):
+    """BASELINE configs[0] at its own size (ml-latest-small shaped synthetic: 610 x 9 724,
+    100 836 ratings split 80/20, f=20, 15 iterations, alpha=40, lamb=0.01 as ALS.py:457):
+    RecommenderALS.train() against the float64 oracle run from the same seed-42 init.
+    Bars: factors 1e-4 relative after the 15th iteration; MAP@200 (the reference's eval.csv
+    score), precision@10 and RMSE on the held-out entries identical to 3 decimals."""
+    from recommender_amd import data, metrics
+    N, M, f, lamb, alpha, iters = 610, 9724, 20, 0.01, 40.0, 15
+    keys, r = data.synth_pairs(N, M, 100836, seed=1234, device="cpu")
+    keys, r = keys.numpy(), r.numpy().astype(np.float64)
+    rng = np.random.default_rng(0)
+    test = rng.random(len(keys)) < 0.2
+    def mat(mask):
+        m = sps.csr_matrix((r[mask], (keys[mask] // M, keys[mask] % M)), shape=(N, M)); m.sort_indices(); return m
+    tr, te = mat(~test), mat(test)
+    rec = ra.RecommenderALS(mode="train", n_users=N, n_items=M,
+                            als_kwargs={"f": f, "lamb": lamb, "alpha": alpha, "epochs": iters})
+    rec.input_data((tr, te))
+    rec.train(evaluate=False)
+    X0, Y0 = als_ref.init_factors(N, M, f, "ref")
+    trt = sps.csr_matrix(tr.T); trt.sort_indices()
+    Xo, Yo = X0, Y0
+    for _ in range(iters):
+        Xo = c_oracle.half_sweep(tr.indptr, tr.indices, tr.data, Yo, Xo, lamb, alpha, nthreads=8)
+        Yo = c_oracle.half_sweep(trt.indptr, trt.indices, trt.data, Xo, Yo, lamb, alpha, nthreads=8)
+    X = rec.X.cpu().numpy().astype(np.float64); Y = rec.Y.cpu().numpy().astype(np.float64)
+    ex = np.abs(X - Xo).max() / np.abs(Xo).max(); ey = np.abs(Y - Yo).max() / np.abs(Yo).max()
+    assert ex < 1e-4 and ey < 1e-4, (ex, ey)
+    users = metrics.users_to_test(tr)
+    score = rec.evaluate(users)
+    oidx, _ = als_ref.recommend_full(Xo, Yo, users)
+    oscore = als_ref.map_at_k(oidx, (te.indptr, te.indices, te.data), (tr.indptr, tr.indices, tr.data), users, 3.0, 200)
+    assert abs(score - oscore) < 5e-4, (score, oscore)
+    # precision@10 over the same users, training items filtered
+    gidx, _ = rec.recommend(users, k=10, filter_rated=True)
+    def prec(idx_rows, filt):
+        hits = []
+        for k, u in enumerate(users):
+            trn = tr.indices[tr.indptr[u]:tr.indptr[u + 1]]
+            row = [i for i in idx_rows[k] if not (filt and i in set(trn))][:10]
+            tst = set(te.indices[te.indptr[u]:te.indptr[u + 1]])
+            hits.append(sum(1 for i in row if i in tst) / 10.0)
+        return float(np.mean(hits))
+    assert abs(prec(gidx, False) - prec(oidx, True)) < 5e-4
+    # RMSE of the predicted preference on the held-out entries (target p = 1)
+    tu, ti = te.nonzero()
+    rg = metrics.rmse(rec.predict(tu, ti), np.ones(len(tu)))
+    ro = als_ref.rmse(np.einsum("ij,ij->i", Xo[tu], Yo[ti]), np.ones(len(tu)))
+    assert abs(rg - ro) < 5e-4, (rg, ro)
