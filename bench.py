@@ -144,9 +144,17 @@ def main():
         wl["f"] = args.factors
     f = wl["f"]
     U, Ut, ub, ib, N, M, nnz = build_shards(wl, world, rank, dev)
-    Xh, Yh = init_factors(N, M, f, "tf")
-    X = torch.from_numpy(Xh.astype(np.float32)).to(dev)
-    Y = torch.from_numpy(Yh.astype(np.float32)).to(dev)
+    if wl.get("init") == "device":      # large shards: same distribution, drawn on the device
+        g = torch.Generator(device=dev); g.manual_seed(42)
+        X = torch.randn((N, f), generator=g, device=dev) / np.sqrt(f)
+        Y = torch.randn((M, f), generator=g, device=dev) / np.sqrt(f)
+        Xh = Yh = None
+    else:
+        Xh, Yh = init_factors(N, M, f, "tf")
+        X = torch.from_numpy(Xh.astype(np.float32)).to(dev)
+        Y = torch.from_numpy(Yh.astype(np.float32)).to(dev)
+    if wl.get("solver") and args.solver == "cholesky" and f > 128:
+        args.solver = wl["solver"]
     csr_u = ops.DeviceCSR(U[0], U[1], U[2], (ub[rank + 1] - ub[rank], M), dev)
     csr_i = ops.DeviceCSR(Ut[0], Ut[1], Ut[2], (ib[rank + 1] - ib[rank], N), dev)
     eng = ALSEngine(csr_u, csr_i, X, Y, wl["lamb"], wl["alpha"], ub, ib, group, solver=args.solver,
@@ -238,7 +246,7 @@ def main():
                          "launch_ms": {"user_sweep": ku, "item_sweep": ki},
                          "algorithmic_bytes_per_launch": (bytes_u + bytes_i) / 2},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and Xh is not None:
             out["cpu_baseline"] = cpu_baseline(U, Ut, Xh, Yh, wl, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:

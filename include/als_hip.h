@@ -38,8 +38,8 @@ extern "C" {
 #define ALS_MAX_FACTORS 256         /* largest f (Gram, conjugate-gradient half-sweep, scoring) */
 #define ALS_MAX_FACTORS_EXACT 128   /* largest f of the exact (Cholesky) half-sweep            */
 #define ALS_DEFAULT_CHUNK_NNZ 2048  /* rows longer than this are split (multiple of 64)        */
-#define ALS_GRAM_CHUNK_ROWS 1024    /* rows per first-level Gram partial                       */
-#define ALS_GRAM_SUPER_ROWS 65536   /* rows per second-level Gram partial (64 chunks)          */
+#define ALS_GRAM_CHUNK_ROWS 256     /* rows per first-level Gram partial                       */
+#define ALS_GRAM_SUPER_ROWS 65536   /* rows per second-level Gram partial (256 chunks)         */
 #define ALS_GRAM_WIDE_CHUNK_ROWS 4096 /* rows per first-level partial when f > ALS_MAX_FACTORS_EXACT */
 
 /* Description of the last error on this thread ("" if none).  Replaces the Python
@@ -86,7 +86,7 @@ int32_t als_plan_fill(const int64_t *rowptr_host, int64_t n_rows, int32_t chunk_
  * gram_out   [device] f*f floats, row major: Y^T Y (no lambda), exactly symmetric.
  * tiles_out  [device] als_gram_tiles_bytes(f) bytes: Y^T Y + lamb*I in the register-tile
  *            order the half-sweep kernel consumes (opaque to the caller).
- * The sum over rows is a fixed three-level tree (1024-row chunks, 64-chunk groups, then
+ * The sum over rows is a fixed three-level tree (256-row chunks, 256-chunk groups, then
  * the groups in order), so a Gram assembled from als_gram_partials_f32 calls on several
  * devices equals the single-device one bit for bit.
  * f > ALS_MAX_FACTORS_EXACT: the same tree over 4096-row chunks of 64 x 64 blocks; tiles_out
@@ -185,6 +185,22 @@ int32_t als_scores_f32(const float *X, int64_t ldx, const int64_t *user_ids, int
                        int64_t M, int32_t f, float *scores, int64_t lds, void *stream);
 int32_t als_topk_rows_f32(float *scores, int64_t lds, int64_t n_rows, int64_t M, const int64_t *ex_rowptr,
                           const int32_t *ex_col, int32_t k, int32_t *idx_out, float *score_out, void *stream);
+/* Fused top-k - the whole of SimpleMFRecAlgo.recommend (RecAlgos.py:20-32) followed by the
+ * "drop rated items, keep the best" filter of RecommenderService.py:16-29, without materialising
+ * the [nu, M] score matrix: the first S items (S >= 65 536) are scored and selected exactly as by
+ * als_scores_f32 + als_topk_rows_f32; their k-th best score is the user's threshold; the
+ * remaining items are scored tile by tile on the matrix cores and only scores above the
+ * threshold leave the registers (to a candidate list of 8192 slots per user); the candidates are
+ * then ordered (score descending, ties by ascending item id).  Same result as the two-call path.
+ * ex_rowptr/ex_col: optional CSR (nu rows, sorted columns) of items to exclude per user.
+ * overflow_out [device] one int32: number of candidates that did not fit a user's list; if it is
+ * not 0 the outputs are not valid and the caller must use the two-call path for these users.
+ * 1 <= k <= min(1024, M); nu <= 65535*64. */
+size_t als_recommend_topk_workspace_bytes(int64_t nu, int64_t M, int32_t k);
+int32_t als_recommend_topk_f32(const float *X, int64_t ldx, const int64_t *user_ids, int64_t nu, const float *Y,
+                               int64_t ldy, int64_t M, int32_t f, int32_t k, const int64_t *ex_rowptr,
+                               const int32_t *ex_col, int32_t *idx_out, float *score_out, int32_t *overflow_out,
+                               void *workspace, size_t ws_bytes, void *stream);
 int32_t als_predict_pairs_f32(const float *X, int64_t ldx, const float *Y, int64_t ldy, const int64_t *u,
                               const int64_t *i, int64_t n, int32_t f, float *out, void *stream);
 int32_t als_normalize_rows_f32(const float *E, int64_t lde, int64_t n, int32_t f, float *out, int64_t ldo,

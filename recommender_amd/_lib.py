@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("ALS_HIP_LIB") or os.path.join(_HERE, "libals_hip.so")
 ALS_OK = 0
 ERROR_NAMES = {1: "invalid argument", 2: "unsupported", 3: "workspace too small", 4: "HIP error"}
 DEFAULT_CHUNK_NNZ = 2048
-GRAM_CHUNK_ROWS = 1024
+GRAM_CHUNK_ROWS = 256
 GRAM_SUPER_ROWS = 65536
 MAX_FACTORS = 256
 MAX_FACTORS_EXACT = 128
@@ -39,6 +39,9 @@ SIGNATURES = {
     "als_profile_tap_next_sweep": (c_i32, [c_vp, c_vp]),
     "als_scores_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_vp]),
     "als_topk_rows_f32": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
+    "als_recommend_topk_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32]),
+    "als_recommend_topk_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp,
+                                       c_vp, c_vp, c_sz, c_vp]),
     "als_predict_pairs_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),
     "als_normalize_rows_f32": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_vp]),
     "als_half_sweep_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32]),

@@ -12,6 +12,7 @@
 //                   Integer LDS atomics only: the result is deterministic.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 
 #include "als_hip.h"
@@ -48,16 +49,47 @@ __device__ __forceinline__ f32x4 load4(const float *__restrict__ row, const int 
     }
 }
 
-template <bool VEC>
+// Candidate lists of the fused top-k: row u holds cap (score, item) slots; slots [0, k) are filled
+// beforehand with the top-k of the first item_begin items, count[u] starts at k.
+struct CandArgs {
+    float *score;
+    int32_t *item;
+    int32_t *count;
+    int32_t *overflow;
+    const int64_t *ex_rowptr;
+    const int32_t *ex_col;
+    int32_t cap, k;
+};
+
+__device__ __forceinline__ bool excluded_item(const CandArgs &c, const int64_t u, const int item) {
+    if (!c.ex_rowptr) return false;
+    int64_t lo = c.ex_rowptr[u], hi = c.ex_rowptr[u + 1];
+    while (lo < hi) {          // the exclusion rows are sorted (canonical CSR)
+        const int64_t mid = (lo + hi) >> 1;
+        const int v = c.ex_col[mid];
+        if (v == item) return true;
+        if (v < item) lo = mid + 1;
+        else hi = mid;
+    }
+    return false;
+}
+
+// FILTER = false: S[u][i] = <X[u], Y[i]> for items [0, M).
+// FILTER = true:  nothing is stored; items are [item_begin, M) and a score strictly above the
+//                 user's threshold (slot k-1 of its candidate row: the k-th best of the earlier
+//                 items) is appended to the candidate row.  An item tied with the threshold cannot
+//                 displace the k earlier items that reach it, because ties rank by ascending id.
+template <bool VEC, bool FILTER>
 __global__ __launch_bounds__(256) void scores_kernel(const float *__restrict__ X, const int64_t ldx,
                                                     const int64_t *__restrict__ user_ids, const int64_t nu,
                                                     const float *__restrict__ Y, const int64_t ldy, const int64_t M,
-                                                    const int f, float *__restrict__ S, const int64_t lds) {
+                                                    const int f, float *__restrict__ S, const int64_t lds,
+                                                    const int64_t item_begin, const CandArgs cand) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, j = lane & 15;
     const int64_t u0 = (int64_t)blockIdx.y * 64;
-    const int64_t i0 = (int64_t)blockIdx.x * 256 + wave * 64;
+    const int64_t i0 = item_begin + (int64_t)blockIdx.x * 256 + wave * 64;
     if (i0 >= M) return;
     const float *xrow[4];
     const float *yrow[4];
@@ -94,10 +126,28 @@ __global__ __launch_bounds__(256) void scores_kernel(const float *__restrict__ X
         for (int r = 0; r < 4; ++r) {
             const int64_t u = u0 + 16 * a + 4 * g + r;
             if (u >= nu) continue;
+            if constexpr (FILTER) {
+                const float tau = cand.score[u * cand.cap + cand.k - 1];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int64_t i = i0 + 16 * b + j;
-                if (i < M) S[u * lds + i] = acc[a][b][r];
+                for (int b = 0; b < 4; ++b) {
+                    const int64_t i = i0 + 16 * b + j;
+                    const float sc = acc[a][b][r];
+                    if (i < M && sc > tau && !excluded_item(cand, u, (int)i)) {
+                        const int pos = atomicAdd(&cand.count[u], 1);      // integer: which slot, not what value
+                        if (pos < cand.cap) {
+                            cand.score[u * cand.cap + pos] = sc;
+                            cand.item[u * cand.cap + pos] = (int32_t)i;
+                        } else {
+                            atomicAdd(cand.overflow, 1);
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int64_t i = i0 + 16 * b + j;
+                    if (i < M) S[u * lds + i] = acc[a][b][r];
+                }
             }
         }
 }
@@ -119,7 +169,8 @@ constexpr int TOPK_MAX = 1024;
 __global__ __launch_bounds__(256) void topk_rows_kernel(float *__restrict__ S, const int64_t lds, const int64_t M,
                                                        const int64_t *__restrict__ ex_rowptr,
                                                        const int32_t *__restrict__ ex_col, const int k,
-                                                       int32_t *__restrict__ idx_out, float *__restrict__ score_out) {
+                                                       int32_t *__restrict__ idx_out, float *__restrict__ score_out,
+                                                       const int64_t out_stride) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t sel_key[TOPK_MAX];
     __shared__ int32_t sel_idx[TOPK_MAX];
@@ -238,9 +289,59 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(float *__restrict__ S, c
         }
     }
     for (int q = tid; q < k; q += 256) {
-        idx_out[(int64_t)blockIdx.x * k + q] = sel_idx[q];
-        score_out[(int64_t)blockIdx.x * k + q] = key_to_float(sel_key[q]);
+        idx_out[(int64_t)blockIdx.x * out_stride + q] = sel_idx[q];
+        score_out[(int64_t)blockIdx.x * out_stride + q] = key_to_float(sel_key[q]);
     }
+}
+
+// Final selection of the fused top-k: one workgroup per user sorts the user's candidates
+// (score descending, item id ascending - the order does not depend on the order of arrival)
+// in LDS and writes the first k.
+constexpr int CAND_CAP = 8192;
+__global__ __launch_bounds__(256) void select_candidates_kernel(const float *__restrict__ cscore,
+                                                               const int32_t *__restrict__ citem,
+                                                               const int32_t *__restrict__ count, const int cap,
+                                                               const int k, int32_t *__restrict__ idx_out,
+                                                               float *__restrict__ score_out) {
+    __shared__ uint32_t key[CAND_CAP];
+    __shared__ int32_t item[CAND_CAP];
+    const int tid = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    const int n = min(count[row], cap);
+    int n2 = 1;
+    while (n2 < n) n2 <<= 1;
+    for (int q = tid; q < n2; q += 256) {
+        const bool ok = q < n;
+        key[q] = ok ? order_key(cscore[row * cap + q]) : 0u;
+        item[q] = ok ? citem[row * cap + q] : INT32_MAX;
+    }
+    __syncthreads();
+    for (int size = 2; size <= n2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int q = tid; q < n2 / 2; q += 256) {
+                const int lo = 2 * q - (q & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const uint32_t ka = key[lo], kb = key[hi];
+                const int32_t ia = item[lo], ib = item[hi];
+                const bool a_first = (ka > kb) || (ka == kb && ia < ib);
+                if (a_first != desc) {
+                    key[lo] = kb; key[hi] = ka;
+                    item[lo] = ib; item[hi] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int q = tid; q < k; q += 256) {
+        idx_out[row * k + q] = item[q];
+        score_out[row * k + q] = key_to_float(key[q]);
+    }
+}
+
+__global__ void fill_i32_kernel(int32_t *__restrict__ p, const int64_t n, const int32_t v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
 }
 
 // ----------------------------------------------------------------------------- small ops
@@ -290,10 +391,85 @@ int32_t als_scores_f32(const float *X, int64_t ldx, const int64_t *user_ids, int
     const bool vec = (f % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && ((uintptr_t)X % 16 == 0) &&
                      ((uintptr_t)Y % 16 == 0);
     hipStream_t st = (hipStream_t)stream;
+    const CandArgs none{};
     if (vec)
-        hipLaunchKernelGGL(scores_kernel<true>, grid, block, 0, st, X, ldx, user_ids, nu, Y, ldy, M, f, scores, lds);
+        hipLaunchKernelGGL((scores_kernel<true, false>), grid, block, 0, st, X, ldx, user_ids, nu, Y, ldy, M, f, scores, lds,
+                           (int64_t)0, none);
     else
-        hipLaunchKernelGGL(scores_kernel<false>, grid, block, 0, st, X, ldx, user_ids, nu, Y, ldy, M, f, scores, lds);
+        hipLaunchKernelGGL((scores_kernel<false, false>), grid, block, 0, st, X, ldx, user_ids, nu, Y, ldy, M, f, scores,
+                           lds, (int64_t)0, none);
+    ALS_HIP_CHECK2(hipGetLastError());
+    return ALS_OK;
+}
+
+// ----------------------------------------------------------------------------- fused top-k
+static int64_t fused_subset_items(int64_t M, int32_t k) {
+    // enough early items that about k*M/S <= CAND_CAP/4 later items are expected above the threshold
+    int64_t s = std::max<int64_t>(65536, ((int64_t)k * M / (CAND_CAP / 4) + 255) / 256 * 256);
+    return std::min(M, s);
+}
+static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+size_t als_recommend_topk_workspace_bytes(int64_t nu, int64_t M, int32_t k) {
+    if (nu < 1 || M < 1 || k < 1 || k > TOPK_MAX || k > M) return 0;
+    const int64_t S = fused_subset_items(M, k);
+    size_t b = align256((size_t)nu * S * sizeof(float));                  // scores of the early items
+    if (S < M) b += 2 * align256((size_t)nu * CAND_CAP * 4) + align256((size_t)nu * 4);
+    return b + 256;
+}
+
+int32_t als_recommend_topk_f32(const float *X, int64_t ldx, const int64_t *user_ids, int64_t nu, const float *Y,
+                               int64_t ldy, int64_t M, int32_t f, int32_t k, const int64_t *ex_rowptr,
+                               const int32_t *ex_col, int32_t *idx_out, float *score_out, int32_t *overflow_out,
+                               void *workspace, size_t ws_bytes, void *stream) {
+    if (!X || !Y || !idx_out || !score_out || !overflow_out || !workspace)
+        return als_fail_(ALS_ERR_INVALID_ARG, "als_recommend_topk_f32: null pointer");
+    if (nu < 1 || M < 1 || M > INT32_MAX || f < 1 || ldx < f || ldy < f)
+        return als_fail_(ALS_ERR_INVALID_ARG, "als_recommend_topk_f32: bad sizes (nu=%lld M=%lld f=%d)", (long long)nu,
+                         (long long)M, f);
+    if (k < 1 || k > TOPK_MAX || k > M)
+        return als_fail_(ALS_ERR_UNSUPPORTED, "als_recommend_topk_f32: k=%d outside [1, min(%d, M)]", k, TOPK_MAX);
+    if ((ex_rowptr == nullptr) != (ex_col == nullptr))
+        return als_fail_(ALS_ERR_INVALID_ARG, "als_recommend_topk_f32: pass both exclusion arrays or neither");
+    if (nu > 65535LL * 64) return als_fail_(ALS_ERR_UNSUPPORTED, "als_recommend_topk_f32: more than 65535*64 users per call");
+    const size_t need = als_recommend_topk_workspace_bytes(nu, M, k);
+    if (ws_bytes < need) return als_fail_(ALS_ERR_WORKSPACE, "top-k workspace too small: %zu < %zu", ws_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t S = fused_subset_items(M, k);
+    char *ws = (char *)workspace;
+    float *sub = (float *)ws; ws += align256((size_t)nu * S * sizeof(float));
+    // 1. the early items, materialised: scores, exclusions, exact top-k
+    int32_t rc = als_scores_f32(X, ldx, user_ids, nu, Y, ldy, S, f, sub, S, stream);
+    if (rc) return rc;
+    if (S == M) {
+        ALS_HIP_CHECK2(hipMemsetAsync(overflow_out, 0, sizeof(int32_t), st));
+        return als_topk_rows_f32(sub, S, nu, S, ex_rowptr, ex_col, k, idx_out, score_out, stream);
+    }
+    CandArgs c;
+    c.score = (float *)ws; ws += align256((size_t)nu * CAND_CAP * 4);
+    c.item = (int32_t *)ws; ws += align256((size_t)nu * CAND_CAP * 4);
+    c.count = (int32_t *)ws;
+    c.overflow = overflow_out; c.ex_rowptr = ex_rowptr; c.ex_col = ex_col; c.cap = CAND_CAP; c.k = k;
+    ALS_HIP_CHECK2(hipMemsetAsync(overflow_out, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, st, c.count, nu, k);
+    ALS_HIP_CHECK2(hipGetLastError());
+    hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)nu), dim3(256), 0, st, sub, S, S, ex_rowptr, ex_col, k, c.item,
+                       c.score, (int64_t)CAND_CAP);
+    ALS_HIP_CHECK2(hipGetLastError());
+    // 2. the later items: score tiles are compared with the user's threshold in registers, never stored
+    const bool vec = (f % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && ((uintptr_t)X % 16 == 0) &&
+                     ((uintptr_t)Y % 16 == 0);
+    const dim3 grid((unsigned)((M - S + 255) / 256), (unsigned)((nu + 63) / 64)), block(256);
+    if (vec)
+        hipLaunchKernelGGL((scores_kernel<true, true>), grid, block, 0, st, X, ldx, user_ids, nu, Y, ldy, M, f, nullptr,
+                           (int64_t)0, S, c);
+    else
+        hipLaunchKernelGGL((scores_kernel<false, true>), grid, block, 0, st, X, ldx, user_ids, nu, Y, ldy, M, f, nullptr,
+                           (int64_t)0, S, c);
+    ALS_HIP_CHECK2(hipGetLastError());
+    // 3. order each user's candidates and keep k
+    hipLaunchKernelGGL(select_candidates_kernel, dim3((unsigned)nu), dim3(256), 0, st, c.score, c.item, c.count, CAND_CAP,
+                       k, idx_out, score_out);
     ALS_HIP_CHECK2(hipGetLastError());
     return ALS_OK;
 }
@@ -308,7 +484,7 @@ int32_t als_topk_rows_f32(float *scores, int64_t lds, int64_t n_rows, int64_t M,
     if ((ex_rowptr == nullptr) != (ex_col == nullptr))
         return als_fail_(ALS_ERR_INVALID_ARG, "als_topk_rows_f32: pass both exclusion arrays or neither");
     hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, scores, lds, M,
-                       ex_rowptr, ex_col, k, idx_out, score_out);
+                       ex_rowptr, ex_col, k, idx_out, score_out, (int64_t)k);
     ALS_HIP_CHECK2(hipGetLastError());
     return ALS_OK;
 }

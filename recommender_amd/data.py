@@ -89,4 +89,11 @@ WORKLOADS = {
     "c1_ml_small_syn": dict(n_users=610, n_items=9724, nnz=80668, f=20, lamb=0.01, alpha=40.0, iters=15),
     # ml-25m shaped: 162 541 x 59 047, 25 000 095 ratings, f=64
     "c2_ml25m_syn": dict(n_users=162541, n_items=59047, nnz=25000095, f=64, lamb=0.01, alpha=40.0, iters=15),
+    # one GPU's eighth of the 10 M x 1 M, 1 B-entry matrix (f=128): 1.25 M users over all 1 M items.  Both
+    # factor tables (0.5 GB and 0.64 GB) exceed the 256 MB Infinity Cache, so the gathers come from HBM.
+    "c3_shard_syn": dict(n_users=1250000, n_items=1000000, nnz=125000000, f=128, lamb=0.01, alpha=40.0, iters=15,
+                         init="device"),
+    # one GPU's eighth of the 50 M x 5 M, 4 B-entry matrix (f=256, conjugate-gradient solver)
+    "c4_shard_syn": dict(n_users=6250000, n_items=5000000, nnz=500000000, f=256, lamb=0.01, alpha=40.0, iters=15,
+                         init="device", solver="cg"),
 }

@@ -371,28 +371,64 @@ def normalize_rows(E, out=None):
     return out
 
 
-def recommend_topk(X, Y, users, k, M=None, exclude_csr=None, block_users=1024):
-    """Top-k items for `users` (int64 device tensor) without materialising more than
-    block_users x M scores.  exclude_csr: optional (rowptr, col) HOST numpy CSR over ALL users
-    whose columns are filtered per user.  Returns (idx int32 [nu, k], scores [nu, k])."""
+def _block_exclusions(exclude_csr, users_host, device):
+    """Device CSR (rowptr int64, col int32) of the excluded items of the users in users_host."""
+    ptr, col = exclude_csr
+    lens = (ptr[users_host + 1] - ptr[users_host]).astype(np.int64)
+    p = np.zeros(len(users_host) + 1, dtype=np.int64); np.cumsum(lens, out=p[1:])
+    cols = np.concatenate([col[ptr[u]:ptr[u + 1]] for u in users_host]) if p[-1] else np.zeros(0, np.int32)
+    return (torch.from_numpy(p).to(device),
+            torch.from_numpy(np.ascontiguousarray(cols, dtype=np.int32)).to(device)
+            if p[-1] else torch.zeros(1, dtype=torch.int32, device=device))
+
+
+def recommend_topk(X, Y, users, k, M=None, exclude_csr=None, block_users=1024, fused=True):
+    """Top-k items for `users` (int64 device tensor), block_users users at a time.
+    exclude_csr: optional (rowptr, col) HOST numpy CSR over ALL users (sorted columns) whose
+    columns are filtered per user.  Returns (idx int32 [nu, k], scores [nu, k]).
+
+    fused=True: als_recommend_topk_f32 - only the first 65 536+ items of a block are materialised,
+    the rest is filtered in the score kernel's registers.  A block whose candidate lists overflow
+    (reported by the library) is redone by the two-call path, as is everything when fused=False."""
+    ldx = _factor_ld(X, "X"); ldy = _factor_ld(Y, "Y")
     M = Y.shape[0] if M is None else int(M)
+    f = X.shape[1]
+    if Y.shape[1] != f or not (1 <= M <= Y.shape[0]):
+        raise ValueError("factor counts differ or M out of range")
+    _need(users, torch.int64, "users", 1)
     nu = users.shape[0]
+    k = int(k)
+    if not (1 <= k <= min(1024, M)):
+        raise ValueError("k must be in [1, min(1024, M)]")
+    if nu and (int(users.min()) < 0 or int(users.max()) >= X.shape[0]):
+        raise ValueError("user id out of range")
     idx = torch.empty((nu, k), dtype=torch.int32, device=X.device)
     val = torch.empty((nu, k), dtype=torch.float32, device=X.device)
-    buf = torch.empty((min(block_users, nu), M), dtype=torch.float32, device=X.device)
     users_host = users.cpu().numpy() if exclude_csr is not None else None
-    for s in range(0, nu, block_users):
-        e = min(nu, s + block_users)
+    bu = min(block_users, max(nu, 1))
+    buf = None
+    blocks = [(s, min(nu, s + block_users)) for s in range(0, nu, block_users)]
+    exs = {}
+    redo = list(range(len(blocks)))
+    if fused and blocks:
+        ws = torch.empty(lib.als_recommend_topk_workspace_bytes(bu, M, k), dtype=torch.uint8, device=X.device)
+        overflow = torch.zeros(len(blocks), dtype=torch.int32, device=X.device)
+        for b, (s, e) in enumerate(blocks):
+            ex = _block_exclusions(exclude_csr, users_host[s:e], X.device) if exclude_csr is not None else None
+            exs[b] = ex
+            with torch.cuda.device(X.device):
+                check(lib.als_recommend_topk_f32(_ptr(X), ldx, _ptr(users[s:e]), e - s, _ptr(Y), ldy, M, f, k,
+                                                 _ptr(ex[0]) if ex else None, _ptr(ex[1]) if ex else None,
+                                                 _ptr(idx[s:e]), _ptr(val[s:e]), _ptr(overflow[b:b + 1]), _ptr(ws),
+                                                 ws.numel(), _stream()), "als_recommend_topk_f32")
+        redo = torch.nonzero(overflow).flatten().cpu().tolist()       # one synchronisation for all blocks
+    for b in redo:
+        s, e = blocks[b]
+        ex = exs[b] if b in exs else (_block_exclusions(exclude_csr, users_host[s:e], X.device)
+                                      if exclude_csr is not None else None)
+        if buf is None:
+            buf = torch.empty((bu, M), dtype=torch.float32, device=X.device)
         sc = scores(X, Y, users[s:e], M, out=buf)
-        ex = None
-        if exclude_csr is not None:
-            ptr, col = exclude_csr
-            lens = (ptr[users_host[s:e] + 1] - ptr[users_host[s:e]]).astype(np.int64)
-            p = np.zeros(e - s + 1, dtype=np.int64); np.cumsum(lens, out=p[1:])
-            cols = np.concatenate([col[ptr[u]:ptr[u + 1]] for u in users_host[s:e]]) if p[-1] else np.zeros(0, np.int32)
-            ex = (torch.from_numpy(p).to(X.device),
-                  torch.from_numpy(np.ascontiguousarray(cols, dtype=np.int32)).to(X.device)
-                  if p[-1] else torch.zeros(1, dtype=torch.int32, device=X.device))
         i_, v_ = topk_rows(sc, k, ex)
         idx[s:e] = i_; val[s:e] = v_
     return idx, val

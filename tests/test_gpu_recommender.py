@@ -225,3 +225,49 @@ def test_c1_full_training_metrics_to_three_decimals(ra):
     rg = metrics.rmse(rec.predict(tu, ti), np.ones(len(tu)))
     ro = als_ref.rmse(np.einsum("ij,ij->i", Xo[tu], Yo[ti]), np.ones(len(tu)))
     assert abs(rg - ro) < 5e-4, (rg, ro)
+
+
+def _two_call(ra, X, Y, users, k, ex):
+    return ra.ops.recommend_topk(X, Y, users, k, exclude_csr=ex, fused=False)
+
+
+@pytest.mark.parametrize("f,k", [(32, 100), (20, 7), (64, 1024)])
+def test_fused_topk_equals_two_call_path(ra, f, k):
+    """The fused top-k (threshold from the first 65 536 items, the rest filtered in the score
+    kernel's registers) returns exactly what scores + top-k on the materialised matrix returns:
+    same items in the same order (ties by ascending id: factors are quantised so that equal
+    scores abound), same score bits, with and without per-user exclusions."""
+    rng = np.random.default_rng(f + k)
+    nu, M = 150, 200000
+    X = torch.from_numpy(rng.integers(-2, 3, size=(nu, f)).astype(np.float32) / 4).cuda()
+    Y = torch.from_numpy(rng.integers(-2, 3, size=(M, f)).astype(np.float32) / 4).cuda()
+    users = torch.arange(nu, device="cuda")
+    i0, v0 = _two_call(ra, X, Y, users, k, None)
+    i1, v1 = ra.ops.recommend_topk(X, Y, users, k)
+    assert torch.equal(i0, i1) and torch.equal(v0, v1)
+    # exclusions: every user drops its own best 30 items (so the threshold must respect them) plus random ones
+    best = i0[:, :30].cpu().numpy()
+    rows = [np.unique(np.concatenate([best[u], rng.integers(0, M, size=50)])).astype(np.int32) for u in range(nu)]
+    ptr = np.zeros(nu + 1, dtype=np.int64); np.cumsum([len(r) for r in rows], out=ptr[1:])
+    ex = (ptr, np.concatenate(rows))
+    j0, w0 = _two_call(ra, X, Y, users, k, ex)
+    j1, w1 = ra.ops.recommend_topk(X, Y, users, k, exclude_csr=ex)
+    assert torch.equal(j0, j1) and torch.equal(w0, w1)
+    for u in range(0, nu, 37):
+        assert not np.intersect1d(j1[u].cpu().numpy(), rows[u]).size
+
+
+def test_fused_topk_overflow_falls_back(ra):
+    """Adversarial item order: the first 65 536 items all score below the rest, so every later
+    item beats the threshold, the candidate lists overflow and the block is redone by the
+    two-call path - the result is still exact."""
+    rng = np.random.default_rng(3)
+    nu, M, f, k = 70, 100000, 16, 50
+    X = torch.from_numpy(np.abs(rng.normal(size=(nu, f))).astype(np.float32)).cuda()
+    Yh = np.abs(rng.normal(size=(M, f))).astype(np.float32)
+    Yh[:65536] *= 1e-3
+    Y = torch.from_numpy(Yh).cuda()
+    users = torch.arange(nu, device="cuda")
+    i0, v0 = _two_call(ra, X, Y, users, k, None)
+    i1, v1 = ra.ops.recommend_topk(X, Y, users, k)
+    assert torch.equal(i0, i1) and torch.equal(v0, v1)

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Serving-path benchmark (BASELINE configs[4]): top-100 items for a block of users against
+1 M items from f=128 factors, all resident.  Reports users/s and the split between the score
+GEMM (fp32 matrix cores) and the exact top-k selection."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from recommender_amd import ops  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--users", type=int, default=8192)
+    ap.add_argument("--items", type=int, default=1000000)
+    ap.add_argument("--factors", type=int, default=128)
+    ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--block-users", type=int, default=1024)
+    a = ap.parse_args()
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    X = torch.randn((a.users, a.factors), generator=g, device="cuda") / a.factors ** 0.5
+    Y = torch.randn((a.items, a.factors), generator=g, device="cuda") / a.factors ** 0.5
+    users = torch.arange(a.users, device="cuda")
+    ops.recommend_topk(X, Y, users[: a.block_users], a.k, block_users=a.block_users)       # warm-up
+    torch.cuda.synchronize()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    e[0].record()
+    idx, val = ops.recommend_topk(X, Y, users, a.k, block_users=a.block_users)
+    e[1].record()
+    buf = torch.empty((a.block_users, a.items), device="cuda")
+    torch.cuda.synchronize()
+    e[2].record()
+    for s in range(0, a.users, a.block_users):
+        ops.scores(X, Y, users[s:s + a.block_users], a.items, out=buf)
+    e[3].record()
+    torch.cuda.synchronize()
+    total, gemm = e[0].elapsed_time(e[1]), e[2].elapsed_time(e[3])
+    flops = 2.0 * a.users * a.items * a.factors
+    print(json.dumps({"users": a.users, "items": a.items, "f": a.factors, "k": a.k, "ms_total": total,
+                      "users_per_s": a.users / total * 1e3, "ms_score_gemm": gemm,
+                      "gemm_tflops": flops / gemm / 1e9, "gemm_frac_of_fp32_mfma_peak": flops / gemm / 1e9 / 157.3,
+                      "ms_topk": total - gemm}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
