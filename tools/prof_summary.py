@@ -9,7 +9,8 @@ out = sys.argv[1]
 def short(name):
     n = name
     for k in ("sweep_items_kernel", "sweep_long_rows_kernel", "gram_chunk_kernel", "gram_finalize_kernel",
-              "sum_groups_kernel", "sum_to_double_kernel"):
+              "sum_groups_kernel", "sum_to_double_kernel", "cg_items_kernel", "cg_long_rows_kernel", "scores_kernel",
+              "gram_wide_chunk_kernel", "sum_slots_kernel"):
         if k in n:
             return k
     return "other:" + n.replace("void ", "")[:48]
