@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--solver", default="cholesky", choices=["cholesky", "cg"],
                     help="cholesky: exact solve (f <= 128, the default workload); cg: fixed-step conjugate gradient")
     ap.add_argument("--cg-steps", type=int, default=3)
+    ap.add_argument("--accumulate", default="bf16x3", choices=["bf16x3", "fp32"],
+                    help="exact solver: how the per-row normal matrix is accumulated (see include/als_hip.h)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work per half-sweep sample")
     return ap.parse_args()
@@ -139,6 +141,7 @@ def main():
     from recommender_amd.als import ALSEngine, init_factors
     import ctypes
 
+    ops.set_accumulate_mode(args.accumulate)
     wl = dict(data.WORKLOADS[args.workload])
     if args.factors:
         wl["f"] = args.factors
@@ -237,7 +240,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %d users x %d items, %d nnz, f=%d, lamb=%g, alpha=%g, %s"
                                    % (args.workload, N, M, nnz, f, wl["lamb"], wl["alpha"],
-                                      "%d conjugate-gradient steps per row" % args.cg_steps if cg else "exact Cholesky solve"),
+                                      "%d conjugate-gradient steps per row" % args.cg_steps if cg
+                                      else "exact Cholesky solve, %s accumulate" % args.accumulate),
                        "parallelism": "dp%d (user/item row shards, all-gather of factors)" % world},
             "roofline": {"bound": "hbm", "kernel": "cg half-sweep (cg_items_kernel passes + Gram GEMM)" if cg
                          else "sweep_items_kernel (per-row gather/accumulate + solve)",

@@ -49,6 +49,19 @@ const char *als_last_error_string(void);
 /* Library ABI version (bumped on any signature change). */
 int32_t als_abi_version(void);
 
+/* How the exact half-sweep forms  sum_j alpha r_uj y_j y_j^T  for 16 < f <= 128 (process-wide
+ * setting, no reference counterpart):
+ *   ALS_ACCUMULATE_BF16X3 (default)  every value is cut exactly into three bf16 pieces and the six
+ *       significant piece products run on the bf16 matrix cores, accumulated in float32; error
+ *       at the level of float32 rounding (the dropped products are < 2^-23 of each term);
+ *   ALS_ACCUMULATE_FP32              float32 matrix-core fma chain in CSR order (v_mfma_f32_16x16x4_f32).
+ * Both are deterministic and independent of the launch geometry.  f <= 16 always uses FP32, as
+ * does the Gram. */
+#define ALS_ACCUMULATE_FP32 0
+#define ALS_ACCUMULATE_BF16X3 1
+int32_t als_set_accumulate_mode(int32_t mode);
+int32_t als_get_accumulate_mode(void);
+
 /* ------------------------------------------------------------------------------------
  * Row schedule ("plan") - host-side, CPU only, built once per CSR matrix.
  *

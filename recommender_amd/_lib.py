@@ -22,6 +22,7 @@ GRAM_SUPER_ROWS = 65536
 MAX_FACTORS = 256
 MAX_FACTORS_EXACT = 128
 GRAM_WIDE_CHUNK_ROWS = 4096
+ACCUMULATE_FP32, ACCUMULATE_BF16X3 = 0, 1
 
 c_i32, c_i64, c_f32, c_sz, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
 
@@ -29,6 +30,8 @@ c_i32, c_i64, c_f32, c_sz, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 SIGNATURES = {
     "als_last_error_string": (ctypes.c_char_p, []),
     "als_abi_version": (c_i32, []),
+    "als_set_accumulate_mode": (c_i32, [c_i32]),
+    "als_get_accumulate_mode": (c_i32, []),
     "als_plan_count": (c_i32, [c_vp, c_i64, c_i32, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "als_plan_fill": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp]),
     "als_gram_tiles_bytes": (c_sz, [c_i32]),

@@ -45,6 +45,7 @@ namespace {
 // ----------------------------------------------------------------------------- errors
 thread_local char g_err[512] = "";
 thread_local hipEvent_t g_tap_begin = nullptr, g_tap_end = nullptr;
+int g_accumulate_mode = ALS_ACCUMULATE_BF16X3;
 
 int fail(int code, const char *fmt, ...) {
     va_list ap;
@@ -182,16 +183,96 @@ __device__ __forceinline__ void compute(const Stage<VW> &st, f32x4 (&acc)[Geo<VW
     }
 }
 
+// ----------------------------------------------------------------------------- bf16 x 3 accumulate
+// The rank-32 update  sum_k w_k y_k y_k^T  on the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16, 16
+// cycles per 16 x 16 x 32 block against 8 x 32 cycles of the fp32 form, and that pipe runs beside
+// the VALU).  Every value x = sqrt(w_k) y_k[i] is cut into three bf16 pieces by truncation,
+//     hi = x & 0xffff0000,  mid = (x - hi) & 0xffff0000,  lo = (x - hi) - mid,
+// which is exact: x = hi + mid + lo (3 x 8 mantissa bits).  Of the 9 piece products the 6 of
+// relative size >= 2^-16 are kept (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid); the dropped ones
+// are below 2^-23 of the product, i.e. at the rounding of the fp32 result.
+// No data movement is needed: lane (g, j) holds, for its 4 (or 8) factor indices, the entries
+// 4q + g (q = 0..7) of a 32-entry block - exactly the 8 k-slots a lane owns in the A and in the B
+// fragment (slot 8g + q <-> entry 4q + g, the same permutation for both operands).
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int VW>
+struct SplitOps {
+    unsigned H[VW][4], M[VW][4], L[VW][4];   // fragment register r holds k-slots 2r (low half) and 2r + 1
+};
+
+// low half <- high 16 bits of a, high half <- high 16 bits of b (two truncated bf16)
+__device__ __forceinline__ unsigned pack_trunc(const float a, const float b) {
+    return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+__device__ __forceinline__ float trunc_bf16(const float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+
+// Pieces of the GS k-steps of one stage into fragment registers [QB/2, QB/2 + GS/2); also bacc.
+// st.w holds sqrt(alpha r) here.
+template <int VW>
+__device__ __forceinline__ void split_stage(const Stage<VW> &st, const int QB, SplitOps<VW> &o, float (&bacc)[VW]) {
+    constexpr int GS = StageGeo<VW>::GS;
+#pragma unroll
+    for (int p = 0; p < GS / 2; ++p) {
+#pragma unroll
+        for (int t = 0; t < VW; ++t) {
+            const float x0 = st.w[2 * p] * st.v[2 * p][t], x1 = st.w[2 * p + 1] * st.v[2 * p + 1][t];
+            bacc[t] = fmaf(st.cw[2 * p], st.v[2 * p][t], bacc[t]);
+            bacc[t] = fmaf(st.cw[2 * p + 1], st.v[2 * p + 1][t], bacc[t]);
+            const float r0 = x0 - trunc_bf16(x0), r1 = x1 - trunc_bf16(x1);
+            const float l0 = r0 - trunc_bf16(r0), l1 = r1 - trunc_bf16(r1);
+            o.H[t][QB / 2 + p] = pack_trunc(x0, x1);
+            o.M[t][QB / 2 + p] = pack_trunc(r0, r1);
+            o.L[t][QB / 2 + p] = pack_trunc(l0, l1);
+        }
+    }
+}
+template <int VW>
+__device__ __forceinline__ void split_zero(const int QB, SplitOps<VW> &o) {
+    constexpr int GS = StageGeo<VW>::GS;
+#pragma unroll
+    for (int p = 0; p < GS / 2; ++p)
+#pragma unroll
+        for (int t = 0; t < VW; ++t) o.H[t][QB / 2 + p] = o.M[t][QB / 2 + p] = o.L[t][QB / 2 + p] = 0u;
+}
+__device__ __forceinline__ f32x4 mfma_bf16(const unsigned (&a)[4], const unsigned (&b)[4], const f32x4 &c) {
+    const u32x4 av{a[0], a[1], a[2], a[3]}, bv{b[0], b[1], b[2], b[3]};
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
+}
+template <int VW>
+__device__ __forceinline__ void split_mfma_pass(const unsigned (&A)[VW][4], const unsigned (&B)[VW][4],
+                                                f32x4 (&acc)[Geo<VW>::NT]) {
+#pragma unroll
+    for (int ta = 0; ta < VW; ++ta)
+#pragma unroll
+        for (int tb = ta; tb < VW; ++tb) {
+            const int t = tile_index(ta, tb, VW);
+            acc[t] = mfma_bf16(A[ta], B[tb], acc[t]);
+        }
+}
+// one 32-entry block: smallest products first; consecutive MFMAs go to different accumulators
+template <int VW>
+__device__ __forceinline__ void split_block(const SplitOps<VW> &o, f32x4 (&acc)[Geo<VW>::NT]) {
+    split_mfma_pass<VW>(o.L, o.H, acc);
+    split_mfma_pass<VW>(o.H, o.L, acc);
+    split_mfma_pass<VW>(o.M, o.M, acc);
+    split_mfma_pass<VW>(o.M, o.H, acc);
+    split_mfma_pass<VW>(o.H, o.M, acc);
+    split_mfma_pass<VW>(o.H, o.H, acc);
+}
+
 // acc += sum_{e in [s, e)} w_e y_e y_e^T, bacc += sum c_e y_e over CSR entries [s, e) (GATHER)
 // with w = alpha r, c = 1 + alpha r (0 for a stored zero), or over the dense rows [s, e) of Y with
 // w = 1 (!GATHER, the Gram).  s, e are wave uniform, e > s.
-template <int VW, bool VEC, bool FULL, bool GATHER>
+template <int VW, bool VEC, bool FULL, bool GATHER, bool SPLIT = false>
 __device__ __forceinline__ void accumulate_range(f32x4 (&acc)[Geo<VW>::NT], float (&bacc)[VW],
                                                  const int32_t *__restrict__ col, const float *__restrict__ val,
                                                  const int64_t s, const int64_t e, const float *__restrict__ Y,
                                                  const int64_t ld, const int f, const float alpha, const int lane) {
     constexpr int GS = StageGeo<VW>::GS, NG = StageGeo<VW>::NG;
     Stage<VW> A, B;
+    SplitOps<VW> ops;   // only touched when SPLIT
     uint32_t cur_off, nxt_off = 0;
     float cur_w, cur_cw, nxt_w = 0.f, nxt_cw = 0.f;
     const uint32_t ldu = VEC ? (uint32_t)(ld / VecUnit<VW>::W) : 1u;   // row pitch in vector units
@@ -204,7 +285,7 @@ __device__ __forceinline__ void accumulate_range(f32x4 (&acc)[Geo<VW>::NT], floa
             const float rr = val[ii];
             const float ww = alpha * rr;
             off = ok ? (uint32_t)cc * ldu : 0u;
-            w = ok ? ww : 0.f;
+            w = ok ? (SPLIT ? __builtin_sqrtf(ww) : ww) : 0.f;      // SPLIT: both operands carry sqrt(w)
             cw = (ok && rr != 0.f) ? 1.f + ww : 0.f;
         } else {
             off = ok ? (uint32_t)idx * ldu : 0u;
@@ -232,7 +313,16 @@ __device__ __forceinline__ void accumulate_range(f32x4 (&acc)[Geo<VW>::NT], floa
                 cur_cw = nxt_cw;
                 issue<VW, VEC, FULL>(nxt, 0, cur_off, cur_w, cur_cw, Y, ld, f, lane);
             }
-            if (ng > g) compute<VW, GATHER>(cur, acc, bacc);
+            if constexpr (SPLIT) {
+                // a 32-entry block is 8 / GS stages; its MFMAs run when its last stage has been split
+                constexpr int SPB = 8 / GS;                    // stages per block (2 for GS = 4, 1 for GS = 8)
+                const int QB = (g % SPB) * GS;                 // first k-slot of this stage within its block
+                if (ng > g) split_stage<VW>(cur, QB, ops, bacc);
+                else if (ng > g - (g % SPB)) split_zero<VW>(QB, ops);   // block started, this stage is empty
+                if ((g % SPB) == SPB - 1 && ng > g - (g % SPB)) split_block<VW>(ops, acc);
+            } else {
+                if (ng > g) compute<VW, GATHER>(cur, acc, bacc);
+            }
         }
     }
 }
@@ -485,8 +575,12 @@ struct SweepParams {
     float alpha;
 };
 
-template <int VW, bool VEC, bool FULL>
-__global__ __launch_bounds__(64, (VW >= 8 ? ALS_SWEEP_WAVES_F128 : ALS_SWEEP_WAVES)) void sweep_items_kernel(const SweepParams p) {
+#ifndef ALS_SWEEP_WAVES_SPLIT
+#define ALS_SWEEP_WAVES_SPLIT 3  // f <= 64 with the bf16 x 3 accumulate: 48 more registers for the fragments
+#endif
+template <int VW, bool VEC, bool FULL, bool SPLIT>
+__global__ __launch_bounds__(64, (VW >= 8 ? ALS_SWEEP_WAVES_F128 : SPLIT ? ALS_SWEEP_WAVES_SPLIT : ALS_SWEEP_WAVES))
+void sweep_items_kernel(const SweepParams p) {
     using G = Geo<VW>;
     const int lane = threadIdx.x;
     const als_item_t it = p.items[blockIdx.x];
@@ -505,7 +599,7 @@ __global__ __launch_bounds__(64, (VW >= 8 ? ALS_SWEEP_WAVES_F128 : ALS_SWEEP_WAV
 
 #ifndef ALS_ABLATE_NO_ACCUMULATE
     if (e > s) {
-        accumulate_range<VW, VEC, FULL, true>(acc, bacc, p.col, p.val, s, e, p.Y, p.ldy, p.f, p.alpha, lane);
+        accumulate_range<VW, VEC, FULL, true, SPLIT>(acc, bacc, p.col, p.val, s, e, p.Y, p.ldy, p.f, p.alpha, lane);
         reduce_b<VW>(bacc);
     }
 #endif
@@ -713,12 +807,18 @@ static int32_t half_sweep_impl(const SweepParams &p, int64_t n_rows, int64_t n_i
     if (n_items > 0) {
         if (tap0) ALS_HIP_CHECK(hipEventRecord(tap0, st));
         const dim3 grid((unsigned)n_items), block(64);
-        if (vec && p.f == Geo<VW>::FPAD)
-            hipLaunchKernelGGL((sweep_items_kernel<VW, true, true>), grid, block, 0, st, p);
-        else if (vec)
-            hipLaunchKernelGGL((sweep_items_kernel<VW, true, false>), grid, block, 0, st, p);
-        else
-            hipLaunchKernelGGL((sweep_items_kernel<VW, false, false>), grid, block, 0, st, p);
+        constexpr bool CAN_SPLIT = VW >= 4;
+        const bool split = CAN_SPLIT && g_accumulate_mode == ALS_ACCUMULATE_BF16X3;
+        if (vec && p.f == Geo<VW>::FPAD) {
+            if (split) hipLaunchKernelGGL((sweep_items_kernel<VW, true, true, CAN_SPLIT>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((sweep_items_kernel<VW, true, true, false>), grid, block, 0, st, p);
+        } else if (vec) {
+            if (split) hipLaunchKernelGGL((sweep_items_kernel<VW, true, false, CAN_SPLIT>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((sweep_items_kernel<VW, true, false, false>), grid, block, 0, st, p);
+        } else {
+            if (split) hipLaunchKernelGGL((sweep_items_kernel<VW, false, false, CAN_SPLIT>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((sweep_items_kernel<VW, false, false, false>), grid, block, 0, st, p);
+        }
         ALS_HIP_CHECK(hipGetLastError());
         if (tap1) ALS_HIP_CHECK(hipEventRecord(tap1, st));
     }
@@ -767,7 +867,15 @@ int32_t als_profile_tap_next_sweep(void *ev_begin, void *ev_end) {
     g_tap_end = (hipEvent_t)ev_end;
     return ALS_OK;
 }
-int32_t als_abi_version(void) { return 1; }
+int32_t als_abi_version(void) { return 2; }
+
+int32_t als_set_accumulate_mode(int32_t mode) {
+    if (mode != ALS_ACCUMULATE_FP32 && mode != ALS_ACCUMULATE_BF16X3)
+        return fail(ALS_ERR_INVALID_ARG, "als_set_accumulate_mode: unknown mode %d", mode);
+    g_accumulate_mode = mode;
+    return ALS_OK;
+}
+int32_t als_get_accumulate_mode(void) { return g_accumulate_mode; }
 
 // ----------------------------------------------------------------------------- plan
 int32_t als_plan_count(const int64_t *rowptr, int64_t n_rows, int32_t chunk_nnz, int64_t *n_items, int64_t *n_long,

@@ -46,6 +46,19 @@ def _factor_ld(t, name):
     return t.stride(0)
 
 
+def set_accumulate_mode(mode):
+    """"bf16x3" (default): the per-row normal matrix is accumulated on the bf16 matrix cores from an
+    exact 3-way split of every float32 value; "fp32": float32 matrix-core fma chain.  Process-wide."""
+    codes = {"fp32": _lib.ACCUMULATE_FP32, "bf16x3": _lib.ACCUMULATE_BF16X3}
+    if mode not in codes:
+        raise ValueError("mode must be 'fp32' or 'bf16x3'")
+    check(lib.als_set_accumulate_mode(codes[mode]), "als_set_accumulate_mode")
+
+
+def get_accumulate_mode():
+    return {_lib.ACCUMULATE_FP32: "fp32", _lib.ACCUMULATE_BF16X3: "bf16x3"}[lib.als_get_accumulate_mode()]
+
+
 # ----------------------------------------------------------------------------- plan (host only)
 def build_plan(indptr, chunk_nnz=_lib.DEFAULT_CHUNK_NNZ):
     """Row schedule for a CSR row-pointer array (host numpy int64).  Returns
