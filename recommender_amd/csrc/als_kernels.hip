@@ -5,21 +5,19 @@
 //
 //   A 16-lane group g = lane>>4 handles one gathered factor row per k-step, lane
 //   j = lane&15 of the group holds VW = FPAD/16 of its elements (one 16-byte load for
-//   FPAD = 64).  Those registers are directly the A and B operands of
-//   v_mfma_f32_16x16x4_f32 (A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15]), so the
-//   rank-4 update  sum_k w_k y_k y_k^T  of the f x f normal matrix is VW*(VW+1)/2 MFMAs
-//   per 4 gathered rows with no LDS staging and no cross-lane traffic.  Tile (ta, tb)
-//   element (i, j) is matrix element (fidx(i, ta), fidx(j, tb)); only tiles ta <= tb are
-//   computed (symmetry).
+//   FPAD = 64).  In the fp32 mode those registers are directly the A and B operands of
+//   v_mfma_f32_16x16x4_f32 (A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15]); in the default
+//   bf16 x 3 mode eight k-steps are cut into bf16 pieces and fed, again without any data
+//   movement, to v_mfma_f32_16x16x32_bf16 (see "bf16 x 3 accumulate" below).  Either way the
+//   rank-k update  sum_k w_k y_k y_k^T  of the f x f normal matrix needs no LDS staging and no
+//   cross-lane traffic.  Tile (ta, tb) element (i, j) is matrix element
+//   (fidx(i, ta), fidx(j, tb)); only tiles ta <= tb are computed (symmetry).
 //
-//   The MFMA is an exact k-ordered fp32 fma chain, rows are visited in CSR order, long
-//   rows are cut at fixed multiples of chunk_nnz and combined in chunk order: results
-//   do not depend on the launch geometry.
+//   Rows are visited in CSR order, long rows are cut at fixed multiples of chunk_nnz and
+//   combined in chunk order: results do not depend on the launch geometry.
 //
-//   The f x f solve is a right-looking Cholesky with one matrix row per lane held in
-//   registers; pivots and multipliers are broadcast with v_readlane.  LDS is used only
-//   to move the matrix from the MFMA tile layout to the row-per-lane layout and to
-//   transpose L for the back substitution (packed lower triangle: conflict free).
+//   The f x f solve is a right-looking blocked Cholesky that runs on the accumulator tiles in
+//   place (see "blocked solve" below): no LDS, no layout change.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
