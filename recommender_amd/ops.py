@@ -144,6 +144,25 @@ class DeviceCSR:
         return DeviceCSR(ptr - lo, self.col[lo:hi], self.val[lo:hi], (r1 - r0, self.shape[1]), self.device,
                          self.chunk_nnz, ids)
 
+    def transpose(self):
+        """The CSR of the transposed matrix (canonical: sorted columns), built on the device with
+        one key sort - what sps.csr_matrix(U.T) does on the host in the reference's training script
+        (reclibwh/core/ALS.py:432)."""
+        if self.row_ids is not None:
+            raise ValueError("transpose of a row-mapped CSR is not defined")
+        n_rows, n_cols = self.shape
+        if self.nnz == 0:
+            return DeviceCSR(np.zeros(n_cols + 1, np.int64), np.zeros(0, np.int32), np.zeros(0, np.float32),
+                             (n_cols, n_rows), self.device, self.chunk_nnz)
+        rows = torch.repeat_interleave(torch.arange(n_rows, device=self.device, dtype=torch.int64),
+                                       self.rowptr[1:] - self.rowptr[:-1])
+        keys, order = torch.sort(self.col.to(torch.int64) * n_rows + rows)
+        trow = torch.div(keys, n_rows, rounding_mode="floor")
+        ptr = torch.zeros(n_cols + 1, dtype=torch.int64, device=self.device)
+        torch.cumsum(torch.bincount(trow, minlength=n_cols), 0, out=ptr[1:])
+        return DeviceCSR(ptr, (keys - trow * n_rows).to(torch.int32), self.val[order], (n_cols, n_rows), self.device,
+                         self.chunk_nnz)
+
     def workspace_cg(self, f):
         ws = self._ws.get(("cg", f))
         if ws is None:

@@ -108,11 +108,9 @@ class RecommenderALS:
         if self.Utrain is None:
             raise RuntimeError("call input_data() first")
         self._ensure_factors()
-        import scipy.sparse as sps
         c = self.config
-        Ut = sps.csr_matrix(self.Utrain.T); Ut.sort_indices()
         cu = ops.DeviceCSR.from_scipy(self.Utrain, self.device, c["chunk_nnz"])
-        ci = ops.DeviceCSR.from_scipy(Ut, self.device, c["chunk_nnz"])
+        ci = cu.transpose()             # on the device (the reference transposes on the host, ALS.py:432)
         self.engine = ALSEngine(cu, ci, self.X, self.Y, c["lamb"], c["alpha"], solver=c["solver"],
                                 cg_steps=c["cg_steps"])
 

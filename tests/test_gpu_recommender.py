@@ -271,3 +271,16 @@ def test_fused_topk_overflow_falls_back(ra):
     i0, v0 = _two_call(ra, X, Y, users, k, None)
     i1, v1 = ra.ops.recommend_topk(X, Y, users, k)
     assert torch.equal(i0, i1) and torch.equal(v0, v1)
+
+
+def test_device_transpose_equals_scipy(ra):
+    rng = np.random.default_rng(2)
+    U = sps.random(300, 170, density=0.05, random_state=7, format="csr", dtype=np.float64)
+    U.data = rng.integers(1, 11, size=U.nnz) * 0.5
+    U.sort_indices()
+    t = ra.DeviceCSR.from_scipy(U, "cuda").transpose()
+    Ut = sps.csr_matrix(U.T); Ut.sort_indices()
+    assert t.shape == Ut.shape and t.nnz == Ut.nnz
+    assert np.array_equal(t.rowptr.cpu().numpy(), Ut.indptr)
+    assert np.array_equal(t.col.cpu().numpy(), Ut.indices)
+    assert np.array_equal(t.val.cpu().numpy(), Ut.data.astype(np.float32))

@@ -112,3 +112,32 @@ def test_blocked_solve_index_logic_in_emulation():
     emul = importlib.util.module_from_spec(spec); spec.loader.exec_module(emul)
     for VW, f in [(1, 5), (2, 20), (4, 64), (8, 100)]:
         assert emul.run(VW, f, seed=VW) < 2e-4
+
+
+def test_csv_ingest_matches_reference_normalisation(tmp_path):
+    """Raw CSV -> dense ids in sorted-key order (what pandas category codes give, the reference's
+    normalizeDf, utils.py:19-33), 80/20 split, CSR [N, M] float64 with duplicates summed
+    (ItemMetadata.py:402-405); the saved folder reads back to the same matrices."""
+    import pandas as pd
+    import scipy.sparse as sps
+    from recommender_amd.ingest import ExplicitDataFromCSV
+    rng = np.random.default_rng(4)
+    n = 500
+    df = pd.DataFrame({"userId": rng.choice([3, 17, 4, 99, 1000, 42], size=n),
+                       "movieId": rng.choice([10, 7, 260, 1196, 5, 8, 31, 2], size=n),
+                       "rating": rng.integers(1, 11, size=n) * 0.5, "timestamp": np.arange(n)})
+    csv = tmp_path / "ratings.csv"; df.to_csv(csv, index=False)
+    d = ExplicitDataFromCSV(False, ratings_csv=str(csv), seed=1)
+    assert (d.N, d.M, d.Nranked) == (6, 8, n)
+    assert np.array_equal(d.user, df["userId"].astype("category").cat.codes.to_numpy())
+    assert np.array_equal(d.item, df["movieId"].astype("category").cat.codes.to_numpy())
+    tr, te = d.make_training_datasets(dtype="sparse")
+    assert tr.shape == te.shape == (6, 8) and tr.dtype == np.float64
+    assert abs(int((d.split == 0).sum()) - 0.8 * n) <= 1
+    whole = sps.csr_matrix((d.rating, (d.user, d.item)), shape=(6, 8))
+    assert np.allclose((tr + te).toarray(), whole.toarray())
+    d.save(str(tmp_path / "saved"))
+    d2 = ExplicitDataFromCSV(True, data_folder=str(tmp_path / "saved"))
+    tr2, te2 = d2.make_training_datasets(dtype="sparse")
+    assert (d2.N, d2.M) == (6, 8) and (tr2 != tr).nnz == 0 and (te2 != te).nnz == 0
+    assert np.array_equal(d2.user_keys, [3, 4, 17, 42, 99, 1000])
