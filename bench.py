@@ -163,6 +163,7 @@ def main():
     eng = ALSEngine(csr_u, csr_i, X, Y, wl["lamb"], wl["alpha"], ub, ib, group, solver=args.solver,
                     cg_steps=args.cg_steps)
     cg = args.solver == "cg"
+    lockstep = cg and f > 128      # f <= 128: CG runs on the formed matrix inside sweep_items_kernel (one gather pass)
 
     def sync():
         torch.cuda.synchronize()
@@ -183,14 +184,14 @@ def main():
 
     def tap(which):
         e0, e1 = pool.pop(), pool.pop()
-        if cg:      # several kernels per half-sweep: events around the whole call, on the launch stream
+        if lockstep:  # several kernels per half-sweep: events around the whole call, on the launch stream
             e0.record()
         else:       # exact path: the library records the events around the one gather/accumulate/solve kernel
             lib.als_profile_tap_next_sweep(ctypes.c_void_p(e0.cuda_event), ctypes.c_void_p(e1.cuda_event))
         taps[which].append((e0, e1))
 
     def tap_end(which):
-        if cg:
+        if lockstep:
             taps[which][-1][1].record()
 
     eng.post_sweep_hook = tap_end
@@ -213,7 +214,7 @@ def main():
     # nnz*(4 col + 4 val + 4f gathered row) + n_rows*(8 rowptr + 4f written row)
     ku = sum(e0.elapsed_time(e1) for e0, e1 in taps["users"]) / args.steps
     ki = sum(e0.elapsed_time(e1) for e0, e1 in taps["items"]) / args.steps
-    if cg:
+    if lockstep:
         # per half-sweep: cg_steps+1 gather passes over the entries, plus the per-row vectors each pass
         # reads and writes (x, r, p, z and the GEMM's operand and result): see DESIGN.md
         sp = args.cg_steps
@@ -229,6 +230,8 @@ def main():
     if os.path.exists(tpath):
         try:
             traffic = json.load(open(tpath)).get(args.workload + "_f%d" % f + ("_cg" if cg else ""), {}).get("hbm_bytes_per_launch")
+            if args.accumulate != "bf16x3":
+                traffic = None
         except Exception:
             traffic = None
 
@@ -243,8 +246,8 @@ def main():
                                       "%d conjugate-gradient steps per row" % args.cg_steps if cg
                                       else "exact Cholesky solve, %s accumulate" % args.accumulate),
                        "parallelism": "dp%d (user/item row shards, all-gather of factors)" % world},
-            "roofline": {"bound": "hbm", "kernel": "cg half-sweep (cg_items_kernel passes + Gram GEMM)" if cg
-                         else "sweep_items_kernel (per-row gather/accumulate + solve)",
+            "roofline": {"bound": "hbm", "kernel": "cg half-sweep (cg_items_kernel passes + Gram GEMM)" if lockstep
+                         else "sweep_items_kernel (per-row gather/accumulate + %s)" % ("CG on the formed matrix" if cg else "solve"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_ms": (ku + ki) / 2,
                          "launch_ms": {"user_sweep": ku, "item_sweep": ki},

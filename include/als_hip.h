@@ -162,8 +162,17 @@ int32_t als_half_sweep_csr_f32(const int64_t *rowptr, const int32_t *col, const 
  * solver for factor counts whose f x f system no longer fits one wavefront's registers.
  * With cg_steps >= f it reproduces the exact solve to rounding.  A row without entries gets 0.
  *
- * gram     [device] f*f floats, row major: gram_out of als_gram_f32 for Yopp (no lamb).
- * info_out [device] incremented once per (row, step) with p^T A p <= 0 (not positive definite).
+ * Two implementations of the same iteration:
+ *   - f <= ALS_MAX_FACTORS_EXACT and gram_tiles given: ONE gather pass forms the row's matrix in
+ *     the accumulator registers exactly as the exact half-sweep does, and the CG steps run on
+ *     it in place (matrix-vector products on the register tiles);
+ *   - otherwise (f > 128, or gram_tiles == NULL): all rows advance in lock step, cg_steps + 1
+ *     gather passes, the gram part of every step as one GEMM over all rows.
+ *
+ * gram       [device] f*f floats, row major: gram_out of als_gram_f32 for Yopp (no lamb).
+ * gram_tiles [device] tiles_out of the same call (carries lamb), or NULL.
+ * info_out   [device] incremented once per row (first form) or per (row, step) (second form)
+ *            that met p^T A p <= 0 (not positive definite).
  * Other arguments as for als_half_sweep_csr_f32.
  * ------------------------------------------------------------------------------------ */
 size_t als_half_sweep_cg_workspace_bytes(int64_t n_rows, int64_t n_slots, int32_t f);
@@ -171,9 +180,9 @@ int32_t als_half_sweep_cg_f32(const int64_t *rowptr, const int32_t *col, const f
                               const int64_t *row_ids, const als_item_t *items, int64_t n_items,
                               const als_long_row_t *long_rows, int64_t n_long, int64_t n_slots,
                               int32_t chunk_nnz, const float *Yopp, int64_t n_opp, int64_t ldy, const float *gram,
-                              float lamb, int32_t f, float alpha, int32_t cg_steps, float *Xown, int64_t ldx,
-                              double *absdiff_out, int32_t *info_out, void *workspace, size_t ws_bytes,
-                              void *stream);
+                              const float *gram_tiles, float lamb, int32_t f, float alpha, int32_t cg_steps,
+                              float *Xown, int64_t ldx, double *absdiff_out, int32_t *info_out, void *workspace,
+                              size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Scoring - replaces ALSTrainer.predict + SimpleMFRecAlgo.recommend

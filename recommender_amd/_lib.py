@@ -50,7 +50,7 @@ SIGNATURES = {
     "als_half_sweep_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32]),
     "als_half_sweep_cg_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32]),
     "als_half_sweep_cg_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32,
-                                      c_vp, c_i64, c_i64, c_vp, c_f32, c_i32, c_f32, c_i32, c_vp, c_i64, c_vp, c_vp,
+                                      c_vp, c_i64, c_i64, c_vp, c_vp, c_f32, c_i32, c_f32, c_i32, c_vp, c_i64, c_vp, c_vp,
                                       c_vp, c_sz, c_vp]),
     "als_half_sweep_csr_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32,
                                        c_vp, c_i64, c_i64, c_vp, c_i32, c_f32, c_vp, c_i64, c_vp, c_vp, c_vp, c_sz,

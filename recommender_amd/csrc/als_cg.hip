@@ -25,6 +25,12 @@
 
 int als_fail_(int code, const char *fmt, ...);   // als_kernels.hip
 int32_t als_sum_rowdiff_(const float *rowdiff, int64_t n_rows, double *partials, double *out, hipStream_t st);  // als_kernels.hip
+int32_t als_half_sweep_tiles_(const int64_t *rowptr, const int32_t *col, const float *val, int64_t n_rows,
+                              const int64_t *row_ids, const als_item_t *items, int64_t n_items,
+                              const als_long_row_t *long_rows, int64_t n_long, int64_t n_slots, int32_t chunk_nnz,
+                              const float *Yopp, int64_t n_opp, int64_t ldy, const float *gram_tiles, int32_t f,
+                              float alpha, int32_t cg_steps, float *Xown, int64_t ldx, double *absdiff_out,
+                              int32_t *info_out, void *workspace, size_t ws_bytes, void *stream);          // als_kernels.hip
 
 #define ALS_HIP_CHECK3(expr)                                                                      \
     do {                                                                                          \
@@ -549,15 +555,23 @@ size_t als_half_sweep_cg_workspace_bytes(int64_t n_rows, int64_t n_slots, int32_
     b += align_up((size_t)n_rows * sizeof(float), 256) * 2;
     b += align_up((size_t)n_slots * 16 * cg_vw_for(f) * sizeof(float), 256);
     b += align_up((size_t)(ceil_div(n_rows, 8192) + 1) * sizeof(double), 256);
-    return b + 256;
+    b += 256;
+    // f <= ALS_MAX_FACTORS_EXACT with gram_tiles given runs on the accumulator tiles: that path's workspace
+    if (f <= ALS_MAX_FACTORS_EXACT) b = std::max(b, als_half_sweep_workspace_bytes(n_rows, n_slots, f));
+    return b;
 }
 
 int32_t als_half_sweep_cg_f32(const int64_t *rowptr, const int32_t *col, const float *val, int64_t n_rows,
                               const int64_t *row_ids, const als_item_t *items, int64_t n_items,
                               const als_long_row_t *long_rows, int64_t n_long, int64_t n_slots, int32_t chunk_nnz,
-                              const float *Yopp, int64_t n_opp, int64_t ldy, const float *gram, float lamb, int32_t f,
-                              float alpha, int32_t cg_steps, float *Xown, int64_t ldx, double *absdiff_out,
-                              int32_t *info_out, void *workspace, size_t ws_bytes, void *stream) {
+                              const float *Yopp, int64_t n_opp, int64_t ldy, const float *gram, const float *gram_tiles,
+                              float lamb, int32_t f, float alpha, int32_t cg_steps, float *Xown, int64_t ldx,
+                              double *absdiff_out, int32_t *info_out, void *workspace, size_t ws_bytes, void *stream) {
+    if (cg_steps < 1 || cg_steps > 1024) return als_fail_(ALS_ERR_INVALID_ARG, "cg_steps=%d outside [1, 1024]", cg_steps);
+    if (gram_tiles && f <= ALS_MAX_FACTORS_EXACT)      // one gather pass: form the row's matrix, iterate in registers
+        return als_half_sweep_tiles_(rowptr, col, val, n_rows, row_ids, items, n_items, long_rows, n_long, n_slots,
+                                     chunk_nnz, Yopp, n_opp, ldy, gram_tiles, f, alpha, cg_steps, Xown, ldx, absdiff_out,
+                                     info_out, workspace, ws_bytes, stream);
     if (!rowptr || !col || !val || !items || !Yopp || !gram || !Xown || !workspace)
         return als_fail_(ALS_ERR_INVALID_ARG, "als_half_sweep_cg_f32: null pointer");
     if (n_rows < 1 || n_rows > INT32_MAX || n_items < n_rows || n_long < 0 || n_slots < 0 || n_opp < 1)
@@ -568,7 +582,6 @@ int32_t als_half_sweep_cg_f32(const int64_t *rowptr, const int32_t *col, const f
                          (long long)n_items, (long long)n_long, (long long)n_slots);
     if (chunk_nnz < 64 || chunk_nnz % 64) return als_fail_(ALS_ERR_INVALID_ARG, "chunk_nnz must be a positive multiple of 64");
     if (f < 1 || f > ALS_MAX_FACTORS) return als_fail_(ALS_ERR_UNSUPPORTED, "f=%d outside [1, %d]", f, ALS_MAX_FACTORS);
-    if (cg_steps < 1 || cg_steps > 1024) return als_fail_(ALS_ERR_INVALID_ARG, "cg_steps=%d outside [1, 1024]", cg_steps);
     if (ldy < f || ldx < f) return als_fail_(ALS_ERR_INVALID_ARG, "leading dimension smaller than f");
     if (n_items > 0x7fffffffLL) return als_fail_(ALS_ERR_UNSUPPORTED, "too many work items for one launch");
     if (ws_bytes < als_half_sweep_cg_workspace_bytes(n_rows, n_slots, f))

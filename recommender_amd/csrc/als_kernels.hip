@@ -30,6 +30,12 @@
 #include "als_hip.h"
 
 int32_t als_sum_rowdiff_(const float *rowdiff, int64_t n_rows, double *partials, double *out, hipStream_t st);
+int32_t als_half_sweep_tiles_(const int64_t *rowptr, const int32_t *col, const float *val, int64_t n_rows,
+                              const int64_t *row_ids, const als_item_t *items, int64_t n_items,
+                              const als_long_row_t *long_rows, int64_t n_long, int64_t n_slots, int32_t chunk_nnz,
+                              const float *Yopp, int64_t n_opp, int64_t ldy, const float *gram_tiles, int32_t f,
+                              float alpha, int32_t cg_steps, float *Xown, int64_t ldx, double *absdiff_out,
+                              int32_t *info_out, void *workspace, size_t ws_bytes, void *stream);
 // wide Gram (128 < f <= 256), als_cg.hip
 size_t als_gram_wide_tiles_bytes_(int f);
 size_t als_gram_wide_workspace_bytes_(int64_t n, int f);
@@ -522,11 +528,90 @@ __device__ __forceinline__ bool blocked_solve(f32x4 (&T)[Geo<VW>::NT], float (&b
     return ok;
 }
 
+// ----------------------------------------------------------------------------- CG on the formed matrix
+// y = T v for the symmetric block matrix in tile storage (tiles ta <= tb; block (tb, ta) is the
+// transpose of tile (ta, tb)).  v and y are column indexed per block.  The per-lane products of
+// every block row are summed first and reduced across lanes once per block.
+template <int VW>
+__device__ __forceinline__ void sym_tiles_matvec(const f32x4 (&T)[Geo<VW>::NT], const float (&v)[VW], float (&y)[VW],
+                                                 const int lane) {
+    f32x4 vrow[VW], orow[VW];
+    float ocol[VW];
+#pragma unroll
+    for (int t = 0; t < VW; ++t) {
+        vrow[t] = vec_col_to_row(v[t], lane);
+        orow[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ocol[t] = 0.f;
+    }
+#pragma unroll
+    for (int ib = 0; ib < VW; ++ib)
+#pragma unroll
+        for (int jb = ib; jb < VW; ++jb) {
+            const f32x4 &t = T[tile_index(ib, jb, VW)];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) orow[ib][r] = fmaf(t[r], v[jb], orow[ib][r]);         // (T v)[4g + r], before the lane sum
+            if (jb > ib) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ocol[jb] = fmaf(t[r], vrow[ib][r], ocol[jb]);     // (T^T v)[c], before the group sum
+            }
+        }
+#pragma unroll
+    for (int ib = 0; ib < VW; ++ib) {
+        f32x4 srow;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) srow[r] = row_sum16(orow[ib][r]);
+        y[ib] = vec_row_to_col(srow, lane) + grp_sum4(ocol[ib]);
+    }
+}
+template <int VW>
+__device__ __forceinline__ float col_dot(const float (&a)[VW], const float (&b)[VW]) {
+    float d = a[0] * b[0];
+#pragma unroll
+    for (int t = 1; t < VW; ++t) d = fmaf(a[t], b[t], d);
+    return row_sum16(d);      // the same bits in every lane (vectors are replicated over the lane groups)
+}
+// `steps` conjugate-gradient steps on T x = b from the start value x (column indexed, updated in
+// place).  T is not modified.  Returns false if a step met p^T T p <= 0 with a non-zero residual.
+// A step that cannot be taken (zero residual, or not positive definite) ends the iteration.
+template <int VW>
+__device__ __forceinline__ bool tiles_cg(const f32x4 (&T)[Geo<VW>::NT], const float (&b)[VW], float (&x)[VW],
+                                         const int steps, const int lane) {
+    float r[VW], pv[VW], q[VW];
+    sym_tiles_matvec<VW>(T, x, q, lane);
+#pragma unroll
+    for (int t = 0; t < VW; ++t) {
+        r[t] = b[t] - q[t];
+        pv[t] = r[t];
+    }
+    float rs = col_dot<VW>(r, r);
+    bool spd = true;
+    for (int s = 0; s < steps; ++s) {
+        sym_tiles_matvec<VW>(T, pv, q, lane);
+        const float pAp = col_dot<VW>(pv, q);
+        const bool ok = rs > 0.f && pAp > 0.f;
+        spd = spd && !(rs > 0.f && !(pAp > 0.f));
+        const float a = ok ? rs / pAp : 0.f;
+#pragma unroll
+        for (int t = 0; t < VW; ++t) {
+            x[t] = fmaf(a, pv[t], x[t]);
+            r[t] = fmaf(-a, q[t], r[t]);
+        }
+        const float rr = col_dot<VW>(r, r);
+        const float beta = ok ? rr / rs : 0.f;
+#pragma unroll
+        for (int t = 0; t < VW; ++t) pv[t] = fmaf(beta, pv[t], r[t]);
+        rs = ok ? rr : 0.f;
+    }
+    return spd;
+}
+
 // (acc + gram_tiles) x = b for one row; writes x to xrow and returns sum |x_old - x_new| (all lanes).
+// cg_steps == 0: blocked Cholesky; > 0: that many CG steps from the row's current value.
 template <int VW>
 __device__ __forceinline__ float solve_row_blocked(f32x4 (&acc)[Geo<VW>::NT], float (&bacc)[VW],
                                                    const float *__restrict__ gtiles, const int f,
-                                                   float *__restrict__ xrow, int32_t *info, const int lane) {
+                                                   float *__restrict__ xrow, int32_t *info, const int cg_steps,
+                                                   const int lane) {
 #pragma unroll
     for (int t = 0; t < Geo<VW>::NT; ++t) {
 #pragma unroll
@@ -534,16 +619,28 @@ __device__ __forceinline__ float solve_row_blocked(f32x4 (&acc)[Geo<VW>::NT], fl
         // keep the scheduler from hoisting all NT*4 loads to the top (they would need as many registers)
         if (t % 4 == 3) __builtin_amdgcn_sched_barrier(0);
     }
-    float x[VW];
-    const bool ok = blocked_solve<VW>(acc, bacc, x, lane);
     const int j = lane & 15;
+    float x[VW], xold[VW];
+#pragma unroll
+    for (int t = 0; t < VW; ++t) {
+        const int idx = fidx<VW>(j, t);
+        xold[t] = idx < f ? xrow[idx] : 0.f;
+    }
+    bool ok;
+    if (cg_steps > 0) {
+#pragma unroll
+        for (int t = 0; t < VW; ++t) x[t] = xold[t];
+        ok = tiles_cg<VW>(acc, bacc, x, cg_steps, lane);
+    } else {
+        ok = blocked_solve<VW>(acc, bacc, x, lane);
+    }
     float d = 0.f;
     if (lane < 16) {
 #pragma unroll
         for (int t = 0; t < VW; ++t) {
             const int idx = fidx<VW>(j, t);
             if (idx < f) {
-                d += fabsf(xrow[idx] - x[t]);
+                d += fabsf(xold[t] - x[t]);
                 xrow[idx] = x[t];
             }
         }
@@ -571,6 +668,7 @@ struct SweepParams {
     int64_t ldy, ldx;
     int32_t f, chunk_nnz;
     float alpha;
+    int32_t cg_steps;   // 0: exact solve
 };
 
 #ifndef ALS_SWEEP_WAVES_SPLIT
@@ -623,7 +721,7 @@ void sweep_items_kernel(const SweepParams p) {
     } else {
 #else
     if (e > s) {
-        d = solve_row_blocked<VW>(acc, bacc, p.gtiles, p.f, xrow, p.info, lane);
+        d = solve_row_blocked<VW>(acc, bacc, p.gtiles, p.f, xrow, p.info, p.cg_steps, lane);
     } else {
 #endif  // no entries: b = 0, so x = 0 exactly
         d = 0.f;
@@ -668,7 +766,7 @@ __global__ __launch_bounds__(64) void sweep_long_rows_kernel(const SweepParams p
     for (int t = 0; t < VW; ++t) bacc[t] = P[(G::TQ + t) * 64 + lane];
     const int row = lr.row;
     const int64_t xr = p.row_ids ? p.row_ids[row] : (int64_t)row;
-    const float d = solve_row_blocked<VW>(acc, bacc, p.gtiles, p.f, p.X + xr * p.ldx, p.info, lane);
+    const float d = solve_row_blocked<VW>(acc, bacc, p.gtiles, p.f, p.X + xr * p.ldx, p.info, p.cg_steps, lane);
     if (lane == 0) p.rowdiff[row] = d;
 }
 
@@ -1018,6 +1116,21 @@ int32_t als_half_sweep_csr_f32(const int64_t *rowptr, const int32_t *col, const 
                                const float *Yopp, int64_t n_opp, int64_t ldy, const float *gram_tiles, int32_t f,
                                float alpha, float *Xown, int64_t ldx, double *absdiff_out, int32_t *info_out,
                                void *workspace, size_t ws_bytes, void *stream) {
+    return als_half_sweep_tiles_(rowptr, col, val, n_rows, row_ids, items, n_items, long_rows, n_long, n_slots, chunk_nnz,
+                                 Yopp, n_opp, ldy, gram_tiles, f, alpha, 0, Xown, ldx, absdiff_out, info_out, workspace,
+                                 ws_bytes, stream);
+}
+
+}  // extern "C"
+
+// The half-sweep on the accumulator tiles: cg_steps == 0 solves every row exactly (the C entry point
+// above), cg_steps > 0 takes that many CG steps on the formed matrix (als_half_sweep_cg_f32, als_cg.hip).
+int32_t als_half_sweep_tiles_(const int64_t *rowptr, const int32_t *col, const float *val, int64_t n_rows,
+                              const int64_t *row_ids, const als_item_t *items, int64_t n_items,
+                              const als_long_row_t *long_rows, int64_t n_long, int64_t n_slots, int32_t chunk_nnz,
+                              const float *Yopp, int64_t n_opp, int64_t ldy, const float *gram_tiles, int32_t f,
+                              float alpha, int32_t cg_steps, float *Xown, int64_t ldx, double *absdiff_out,
+                              int32_t *info_out, void *workspace, size_t ws_bytes, void *stream) {
     if (!rowptr || !items || !Yopp || !gram_tiles || !Xown || !workspace)
         return fail(ALS_ERR_INVALID_ARG, "als_half_sweep_csr_f32: null pointer");
     if (n_rows < 1 || n_rows > INT32_MAX || n_items < n_rows || n_long < 0 || n_slots < 0 || n_opp < 1)
@@ -1050,6 +1163,7 @@ int32_t als_half_sweep_csr_f32(const int64_t *rowptr, const int32_t *col, const 
     p.rowdiff = (float *)ws; ws += align_up((size_t)n_rows * sizeof(float), 256);
     double *diff_partials = (double *)ws;
     p.info = info_out; p.ldy = ldy; p.ldx = ldx; p.f = f; p.chunk_nnz = chunk_nnz; p.alpha = alpha;
+    p.cg_steps = cg_steps;
     const bool vec = vec_ok(Yopp, ldy, f, n_opp);
     hipStream_t st = (hipStream_t)stream;
     switch (vw) {
@@ -1059,5 +1173,3 @@ int32_t als_half_sweep_csr_f32(const int64_t *rowptr, const int32_t *col, const 
         default: return half_sweep_impl<8>(p, n_rows, n_items, n_long, absdiff_out, diff_partials, vec, st);
     }
 }
-
-}  // extern "C"

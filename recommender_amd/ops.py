@@ -283,9 +283,11 @@ def half_sweep(csr, Yopp, gram_cache, Xown, alpha, absdiff=None, info=None):
     return absdiff
 
 
-def half_sweep_cg(csr, Yopp, gram_cache, Xown, alpha, cg_steps, absdiff=None, info=None):
+def half_sweep_cg(csr, Yopp, gram_cache, Xown, alpha, cg_steps, absdiff=None, info=None, lock_step=False):
     """One half-sweep by `cg_steps` conjugate-gradient steps per row, warm-started at the current
-    rows of Xown (updated in place).  Same contract as half_sweep otherwise; 1 <= f <= 256."""
+    rows of Xown (updated in place).  Same contract as half_sweep otherwise; 1 <= f <= 256.
+    f <= 128: one gather pass, the steps run on the row's matrix in registers; f > 128 (or
+    lock_step=True): cg_steps + 1 gather passes with all rows in lock step."""
     if not isinstance(csr, DeviceCSR):
         raise ValueError("csr must be a DeviceCSR")
     ldy = _factor_ld(Yopp, "Yopp")
@@ -312,7 +314,8 @@ def half_sweep_cg(csr, Yopp, gram_cache, Xown, alpha, cg_steps, absdiff=None, in
         check(lib.als_half_sweep_cg_f32(
             _ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.val), csr.shape[0], _ptr(csr.row_ids), _ptr(csr.items),
             csr.n_items, _ptr(csr.long_rows), csr.n_long, csr.n_slots, csr.chunk_nnz, _ptr(Yopp), csr.shape[1], ldy,
-            _ptr(gram_cache.gram), float(gram_cache.lamb), f, float(alpha), cg_steps, _ptr(Xown), ldx, _ptr(absdiff),
+            _ptr(gram_cache.gram), None if lock_step else _ptr(gram_cache.tiles), float(gram_cache.lamb), f, float(alpha),
+            cg_steps, _ptr(Xown), ldx, _ptr(absdiff),
             _ptr(info), _ptr(ws), ws.numel(), _stream()), "als_half_sweep_cg_f32")
     return absdiff
 
