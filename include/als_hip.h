@@ -130,7 +130,8 @@ int32_t als_gram_finalize_f32(const float *super_in, int64_t n_super, int32_t f,
  *     x_u = A_u^{-1} b_u            (Cholesky; the reference forms inv(A_u), ALS.py:82,172)
  * X is updated in place (ALS.py:196-197) and *absdiff_out receives
  * sum_u sum_k |x_u,k(old) - x_u,k(new)| (ALS.py:195), accumulated in double.
- * Stored zeros contribute nothing (ALS.py:79); ratings are expected to be > 0.
+ * Stored zeros contribute nothing (ALS.py:79); ratings must be >= 0 (the default accumulate mode
+ * takes sqrt(alpha r); a negative rating gives NaN factors for that row).
  * A row without entries gets x_u = 0.
  *
  * rowptr/col/val [device] CSR with n_rows rows; column indices must lie in [0, n_opp).

@@ -103,6 +103,8 @@ class DeviceCSR:
             raise ValueError("indptr must be non-decreasing")
         if col.numel() and (int(col.min()) < 0 or int(col.max()) >= n_cols):
             raise ValueError("column index out of range [0, %d)" % n_cols)
+        if val.numel() and not bool(torch.all(val >= 0)):      # also rejects NaN
+            raise ValueError("ratings must be >= 0 (confidence 1 + alpha r; the kernels take sqrt(alpha r))")
         self.shape = (n_rows, n_cols)
         self.nnz = int(col.shape[0])
         self.chunk_nnz = int(chunk_nnz)

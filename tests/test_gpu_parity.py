@@ -185,6 +185,8 @@ def test_invalid_arguments_raise(ra):
     dat = np.ones(3, dtype=np.float32)
     with pytest.raises(ValueError):
         ra.DeviceCSR(ptr, ind, dat, (2, 4), "cuda")          # column 5 out of range
+    with pytest.raises(ValueError):
+        ra.DeviceCSR(ptr, ind, np.array([1.0, -0.5, 2.0], dtype=np.float32), (2, 6), "cuda")   # negative rating
     csr = ra.DeviceCSR(ptr, ind, dat, (2, 6), "cuda")
     Y = _dev(rng.normal(size=(6, 8))); X = _dev(rng.normal(size=(2, 8)))
     gc = ra.gram(Y, 0.1)
