@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--solver", default="cholesky", choices=["cholesky", "cg"],
                     help="cholesky: exact solve (f <= 128, the default workload); cg: fixed-step conjugate gradient")
     ap.add_argument("--cg-steps", type=int, default=3)
+    ap.add_argument("--cg-form", default="auto", choices=["auto", "matrix", "lock_step"],
+                    help="cg: on the formed matrix (one gather pass) or all rows in lock step (cg_steps+1 passes); "
+                         "auto = matrix for f <= 128, lock_step above")
     ap.add_argument("--accumulate", default="bf16x3", choices=["bf16x3", "fp32"],
                     help="exact solver: how the per-row normal matrix is accumulated (see include/als_hip.h)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -163,7 +166,10 @@ def main():
     eng = ALSEngine(csr_u, csr_i, X, Y, wl["lamb"], wl["alpha"], ub, ib, group, solver=args.solver,
                     cg_steps=args.cg_steps)
     cg = args.solver == "cg"
-    lockstep = cg and f > 128      # f <= 128: CG runs on the formed matrix inside sweep_items_kernel (one gather pass)
+    lockstep = cg and (args.cg_form == "lock_step" or (args.cg_form == "auto" and f > 128))
+    if cg and args.cg_form != "auto":
+        import functools
+        ops.half_sweep_cg = functools.partial(ops.half_sweep_cg, form=args.cg_form)
 
     def sync():
         torch.cuda.synchronize()
@@ -247,7 +253,8 @@ def main():
                                       else "exact Cholesky solve, %s accumulate" % args.accumulate),
                        "parallelism": "dp%d (user/item row shards, all-gather of factors)" % world},
             "roofline": {"bound": "hbm", "kernel": "cg half-sweep (cg_items_kernel passes + Gram GEMM)" if lockstep
-                         else "sweep_items_kernel (per-row gather/accumulate + %s)" % ("CG on the formed matrix" if cg else "solve"),
+                         else "%s (per-row gather/accumulate + %s)" % ("wide_row_items_kernel" if f > 128 else "sweep_items_kernel",
+                                                                       "CG on the formed matrix" if cg else "solve"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_ms": (ku + ki) / 2,
                          "launch_ms": {"user_sweep": ku, "item_sweep": ki},

@@ -163,27 +163,35 @@ int32_t als_half_sweep_csr_f32(const int64_t *rowptr, const int32_t *col, const 
  * solver for factor counts whose f x f system no longer fits one wavefront's registers.
  * With cg_steps >= f it reproduces the exact solve to rounding.  A row without entries gets 0.
  *
- * Two implementations of the same iteration:
- *   - f <= ALS_MAX_FACTORS_EXACT and gram_tiles given: ONE gather pass forms the row's matrix in
- *     the accumulator registers exactly as the exact half-sweep does, and the CG steps run on
- *     it in place (matrix-vector products on the register tiles);
- *   - otherwise (f > 128, or gram_tiles == NULL): all rows advance in lock step, cg_steps + 1
- *     gather passes, the gram part of every step as one GEMM over all rows.
+ * Implementations of the same iteration, chosen by `form`:
+ *   ALS_CG_FORM_MATRIX     ONE gather pass forms the row's matrix in accumulator registers exactly as
+ *                          the exact half-sweep does, and the CG steps run on it in place
+ *                          (matrix-vector products on the register tiles).  f <= 128: one wave per
+ *                          row.  128 < f <= 256: the tiles are spread over the 4 waves of a
+ *                          workgroup and only f-vectors cross waves (through LDS); this costs
+ *                          O(nnz f^2) per row and pays only for rows much longer than f.
+ *                          Needs gram_tiles.
+ *   ALS_CG_FORM_LOCK_STEP  all rows advance in lock step, cg_steps + 1 gather passes, the Gram part
+ *                          of every step as one GEMM over all rows: O(cg_steps (nnz f + f^2)) per row.
+ *   ALS_CG_FORM_AUTO       MATRIX for f <= 128 when gram_tiles is given, else LOCK_STEP.
  *
  * gram       [device] f*f floats, row major: gram_out of als_gram_f32 for Yopp (no lamb).
  * gram_tiles [device] tiles_out of the same call (carries lamb), or NULL.
- * info_out   [device] incremented once per row (first form) or per (row, step) (second form)
- *            that met p^T A p <= 0 (not positive definite).
+ * info_out   [device] incremented once per row (MATRIX) or per (row, step) (LOCK_STEP) that met
+ *            p^T A p <= 0 (not positive definite).
  * Other arguments as for als_half_sweep_csr_f32.
  * ------------------------------------------------------------------------------------ */
+#define ALS_CG_FORM_AUTO 0
+#define ALS_CG_FORM_LOCK_STEP 1
+#define ALS_CG_FORM_MATRIX 2
 size_t als_half_sweep_cg_workspace_bytes(int64_t n_rows, int64_t n_slots, int32_t f);
 int32_t als_half_sweep_cg_f32(const int64_t *rowptr, const int32_t *col, const float *val, int64_t n_rows,
                               const int64_t *row_ids, const als_item_t *items, int64_t n_items,
                               const als_long_row_t *long_rows, int64_t n_long, int64_t n_slots,
                               int32_t chunk_nnz, const float *Yopp, int64_t n_opp, int64_t ldy, const float *gram,
                               const float *gram_tiles, float lamb, int32_t f, float alpha, int32_t cg_steps,
-                              float *Xown, int64_t ldx, double *absdiff_out, int32_t *info_out, void *workspace,
-                              size_t ws_bytes, void *stream);
+                              int32_t form, float *Xown, int64_t ldx, double *absdiff_out, int32_t *info_out,
+                              void *workspace, size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Scoring - replaces ALSTrainer.predict + SimpleMFRecAlgo.recommend

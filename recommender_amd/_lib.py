@@ -23,6 +23,7 @@ MAX_FACTORS = 256
 MAX_FACTORS_EXACT = 128
 GRAM_WIDE_CHUNK_ROWS = 4096
 ACCUMULATE_FP32, ACCUMULATE_BF16X3 = 0, 1
+CG_FORMS = {"auto": 0, "lock_step": 1, "matrix": 2}
 
 c_i32, c_i64, c_f32, c_sz, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
 
@@ -50,8 +51,8 @@ SIGNATURES = {
     "als_half_sweep_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32]),
     "als_half_sweep_cg_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32]),
     "als_half_sweep_cg_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32,
-                                      c_vp, c_i64, c_i64, c_vp, c_vp, c_f32, c_i32, c_f32, c_i32, c_vp, c_i64, c_vp, c_vp,
-                                      c_vp, c_sz, c_vp]),
+                                      c_vp, c_i64, c_i64, c_vp, c_vp, c_f32, c_i32, c_f32, c_i32, c_i32, c_vp, c_i64, c_vp,
+                                      c_vp, c_vp, c_sz, c_vp]),
     "als_half_sweep_csr_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32,
                                        c_vp, c_i64, c_i64, c_vp, c_i32, c_f32, c_vp, c_i64, c_vp, c_vp, c_vp, c_sz,
                                        c_vp]),

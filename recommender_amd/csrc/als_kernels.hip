@@ -669,6 +669,7 @@ struct SweepParams {
     int32_t f, chunk_nnz;
     float alpha;
     int32_t cg_steps;   // 0: exact solve
+    float lamb;         // only the f > 128 kernels read it (for f <= 128 the Gram tiles carry it)
 };
 
 #ifndef ALS_SWEEP_WAVES_SPLIT
@@ -852,6 +853,8 @@ __global__ __launch_bounds__(256) void sum_to_double_kernel(const T *__restrict_
     }
     if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
 }
+
+#include "als_wide_row.inc"
 
 // ----------------------------------------------------------------------------- host helpers
 inline int vw_for(int f) { return f <= 16 ? 1 : f <= 32 ? 2 : f <= 64 ? 4 : 8; }
@@ -1172,4 +1175,62 @@ int32_t als_half_sweep_tiles_(const int64_t *rowptr, const int32_t *col, const f
         case 4: return half_sweep_impl<4>(p, n_rows, n_items, n_long, absdiff_out, diff_partials, vec, st);
         default: return half_sweep_impl<8>(p, n_rows, n_items, n_long, absdiff_out, diff_partials, vec, st);
     }
+}
+
+// 128 < f <= 256: CG on the formed matrix, one row per 4-wave workgroup (als_wide_row.inc).
+size_t als_half_sweep_wide_workspace_bytes_(int64_t n_rows, int64_t n_slots) {
+    size_t b = align_up((size_t)n_slots * WR_SLOT_FLOATS * sizeof(float), 256);
+    b += align_up((size_t)n_rows * sizeof(float), 256);
+    b += align_up((size_t)(ceil_div(n_rows, DIFF_BLOCK_ROWS) + 1) * sizeof(double), 256);
+    return b + 256;
+}
+int32_t als_half_sweep_wide_(const int64_t *rowptr, const int32_t *col, const float *val, int64_t n_rows,
+                             const int64_t *row_ids, const als_item_t *items, int64_t n_items,
+                             const als_long_row_t *long_rows, int64_t n_long, int64_t n_slots, int32_t chunk_nnz,
+                             const float *Yopp, int64_t n_opp, int64_t ldy, const float *gram_tiles, float lamb, int32_t f,
+                             float alpha, int32_t cg_steps, float *Xown, int64_t ldx, double *absdiff_out,
+                             int32_t *info_out, void *workspace, size_t ws_bytes, void *stream) {
+    if (!rowptr || !col || !val || !items || !Yopp || !gram_tiles || !Xown || !workspace)
+        return fail(ALS_ERR_INVALID_ARG, "als_half_sweep_cg_f32: null pointer");
+    if (n_rows < 1 || n_rows > INT32_MAX || n_items < n_rows || n_long < 0 || n_slots < 0 || n_opp < 1)
+        return fail(ALS_ERR_INVALID_ARG, "als_half_sweep_cg_f32: bad sizes (n_rows=%lld n_items=%lld n_opp=%lld)",
+                    (long long)n_rows, (long long)n_items, (long long)n_opp);
+    if ((n_long > 0 && !long_rows) || (n_long > 0) != (n_slots > 0) || n_items != n_rows - n_long + n_slots)
+        return fail(ALS_ERR_INVALID_ARG, "plan sizes are inconsistent (n_items=%lld n_long=%lld n_slots=%lld)",
+                    (long long)n_items, (long long)n_long, (long long)n_slots);
+    if (chunk_nnz < 64 || chunk_nnz % 64) return fail(ALS_ERR_INVALID_ARG, "chunk_nnz must be a positive multiple of 64");
+    if (f <= ALS_MAX_FACTORS_EXACT || f > ALS_MAX_FACTORS) return fail(ALS_ERR_UNSUPPORTED, "f=%d outside (128, 256]", f);
+    if (ldy < f || ldx < f) return fail(ALS_ERR_INVALID_ARG, "leading dimension smaller than f");
+    if (n_items > 0x7fffffffLL) return fail(ALS_ERR_UNSUPPORTED, "too many work items for one launch");
+    if (ws_bytes < als_half_sweep_wide_workspace_bytes_(n_rows, n_slots))
+        return fail(ALS_ERR_WORKSPACE, "cg workspace too small: %zu < %zu", ws_bytes,
+                    als_half_sweep_wide_workspace_bytes_(n_rows, n_slots));
+    char *ws = (char *)workspace;
+    SweepParams p;
+    p.rowptr = rowptr; p.col = col; p.val = val; p.row_ids = row_ids; p.items = items; p.long_rows = long_rows;
+    p.Y = Yopp; p.gtiles = gram_tiles; p.X = Xown;
+    p.partials = (float *)ws; ws += align_up((size_t)n_slots * WR_SLOT_FLOATS * sizeof(float), 256);
+    p.rowdiff = (float *)ws; ws += align_up((size_t)n_rows * sizeof(float), 256);
+    double *diff_partials = (double *)ws;
+    p.info = info_out; p.ldy = ldy; p.ldx = ldx; p.f = f; p.chunk_nnz = chunk_nnz; p.alpha = alpha;
+    p.cg_steps = cg_steps; p.lamb = lamb;
+    // 16-byte loads: whole vectors inside a row, aligned base, 32-bit row offsets in vector units
+    const bool vec = (f % 4 == 0) && (ldy % 4 == 0) && ((uintptr_t)Yopp % 16 == 0) && (n_opp * (ldy / 4) < 0xffffffffLL);
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t tap0 = g_tap_begin, tap1 = g_tap_end;
+    g_tap_begin = g_tap_end = nullptr;
+    if (tap0) ALS_HIP_CHECK(hipEventRecord(tap0, st));
+    if (vec) hipLaunchKernelGGL(wide_row_items_kernel<true>, dim3((unsigned)n_items), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(wide_row_items_kernel<false>, dim3((unsigned)n_items), dim3(256), 0, st, p);
+    ALS_HIP_CHECK(hipGetLastError());
+    if (tap1) ALS_HIP_CHECK(hipEventRecord(tap1, st));
+    if (n_long > 0) {
+        hipLaunchKernelGGL(sum_slots_kernel, dim3((unsigned)n_long, (unsigned)((WR_SLOT_FLOATS + 255) / 256)), dim3(256), 0,
+                           st, p.partials, p.long_rows, WR_SLOT_FLOATS);
+        ALS_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(wide_row_long_kernel, dim3((unsigned)n_long), dim3(256), 0, st, p);
+        ALS_HIP_CHECK(hipGetLastError());
+    }
+    if (absdiff_out) return als_sum_rowdiff_(p.rowdiff, n_rows, diff_partials, absdiff_out, st);
+    return ALS_OK;
 }

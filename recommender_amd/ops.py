@@ -285,11 +285,14 @@ def half_sweep(csr, Yopp, gram_cache, Xown, alpha, absdiff=None, info=None):
     return absdiff
 
 
-def half_sweep_cg(csr, Yopp, gram_cache, Xown, alpha, cg_steps, absdiff=None, info=None, lock_step=False):
+def half_sweep_cg(csr, Yopp, gram_cache, Xown, alpha, cg_steps, absdiff=None, info=None, form="auto"):
     """One half-sweep by `cg_steps` conjugate-gradient steps per row, warm-started at the current
     rows of Xown (updated in place).  Same contract as half_sweep otherwise; 1 <= f <= 256.
-    f <= 128: one gather pass, the steps run on the row's matrix in registers; f > 128 (or
-    lock_step=True): cg_steps + 1 gather passes with all rows in lock step."""
+    form: "matrix" - one gather pass, the steps run on the row's formed matrix in registers;
+    "lock_step" - cg_steps + 1 gather passes with all rows in lock step; "auto" - matrix for
+    f <= 128, lock_step above (see include/als_hip.h)."""
+    if form not in _lib.CG_FORMS:
+        raise ValueError("form must be one of %s" % sorted(_lib.CG_FORMS))
     if not isinstance(csr, DeviceCSR):
         raise ValueError("csr must be a DeviceCSR")
     ldy = _factor_ld(Yopp, "Yopp")
@@ -316,8 +319,8 @@ def half_sweep_cg(csr, Yopp, gram_cache, Xown, alpha, cg_steps, absdiff=None, in
         check(lib.als_half_sweep_cg_f32(
             _ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.val), csr.shape[0], _ptr(csr.row_ids), _ptr(csr.items),
             csr.n_items, _ptr(csr.long_rows), csr.n_long, csr.n_slots, csr.chunk_nnz, _ptr(Yopp), csr.shape[1], ldy,
-            _ptr(gram_cache.gram), None if lock_step else _ptr(gram_cache.tiles), float(gram_cache.lamb), f, float(alpha),
-            cg_steps, _ptr(Xown), ldx, _ptr(absdiff),
+            _ptr(gram_cache.gram), _ptr(gram_cache.tiles), float(gram_cache.lamb), f, float(alpha), cg_steps,
+            _lib.CG_FORMS[form], _ptr(Xown), ldx, _ptr(absdiff),
             _ptr(info), _ptr(ws), ws.numel(), _stream()), "als_half_sweep_cg_f32")
     return absdiff
 

@@ -48,12 +48,12 @@ def _random_csr(rng, N, M, avg, maxlen):
     return ptr, ind, dat
 
 
-def _sweep_cg(ra, ptr, ind, dat, shape, Yfix, Xold, lamb, alpha, steps, chunk_nnz=2048, row_ids=None, lock_step=False):
+def _sweep_cg(ra, ptr, ind, dat, shape, Yfix, Xold, lamb, alpha, steps, chunk_nnz=2048, row_ids=None, form="auto"):
     csr = ra.DeviceCSR(ptr, ind, dat, shape, "cuda", chunk_nnz=chunk_nnz, row_ids=row_ids)
     Y = _dev(Yfix); X = _dev(Xold)
     gc = ra.gram(Y, lamb)
     info = torch.zeros(1, dtype=torch.int32, device="cuda")
-    d = ra.half_sweep_cg(csr, Y, gc, X, alpha, steps, info=info, lock_step=lock_step)
+    d = ra.half_sweep_cg(csr, Y, gc, X, alpha, steps, info=info, form=form)
     torch.cuda.synchronize()
     assert int(info.item()) == 0
     return X.cpu().numpy().astype(np.float64), float(d.item())
@@ -85,28 +85,31 @@ def test_wide_gram_partials_equal_single_call(ra):
 
 
 # ----------------------------------------------------------------------------- CG vs the oracle
-@pytest.mark.parametrize("f,lock_step", [(8, False), (20, False), (20, True), (30, False), (30, True), (64, False),
-                                         (64, True), (100, False), (128, False), (128, True), (192, True), (256, True)])
+@pytest.mark.parametrize("f,form", [(8, "auto"), (20, "matrix"), (20, "lock_step"), (30, "matrix"), (30, "lock_step"),
+                                    (64, "auto"), (64, "lock_step"), (100, "auto"), (128, "matrix"), (128, "lock_step"),
+                                    (192, "auto"), (256, "lock_step"), (130, "matrix"), (160, "matrix"), (192, "matrix"),
+                                    (200, "matrix"), (256, "matrix")])
 @pytest.mark.parametrize("steps", [1, 3])
-def test_cg_matches_oracle_same_steps(ra, f, steps, lock_step):
-    """Both implementations of the iteration: on the formed matrix in registers (f <= 128, one
-    gather pass) and in lock step over all rows (any f, steps + 1 gather passes)."""
+def test_cg_matches_oracle_same_steps(ra, f, steps, form):
+    """All implementations of the iteration: on the formed matrix in one wave's registers (f <= 128)
+    or spread over a 4-wave workgroup (128 < f <= 256), one gather pass each, and in lock step
+    over all rows (any f, steps + 1 gather passes)."""
     rng = np.random.default_rng(500 + f)
     N, M = 600, 900
     ptr, ind, dat = _random_csr(rng, N, M, 30, 850)
     Y0 = rng.normal(0, 1 / np.sqrt(f), size=(M, f)).astype(np.float32)
     X0 = rng.normal(0, 1 / np.sqrt(f), size=(N, f)).astype(np.float32)
     ref = als_ref.half_sweep_cg(ptr, ind, dat, Y0, X0, 0.01, 40.0, steps)
-    X, d = _sweep_cg(ra, ptr, ind, dat, (N, M), Y0, X0, 0.01, 40.0, steps, lock_step=lock_step)
+    X, d = _sweep_cg(ra, ptr, ind, dat, (N, M), Y0, X0, 0.01, 40.0, steps, form=form)
     assert _rel(X, ref) < 2e-4
     assert d == pytest.approx(np.abs(X0.astype(np.float64) - ref).sum(), rel=1e-4)
-    X2, d2 = _sweep_cg(ra, ptr, ind, dat, (N, M), Y0, X0, 0.01, 40.0, steps, lock_step=lock_step)   # bit-for-bit reproducible
+    X2, d2 = _sweep_cg(ra, ptr, ind, dat, (N, M), Y0, X0, 0.01, 40.0, steps, form=form)   # bit-for-bit reproducible
     assert np.array_equal(X, X2) and d == d2
 
 
-@pytest.mark.parametrize("lock_step", [False, True])
+@pytest.mark.parametrize("form", ["matrix", "lock_step"])
 @pytest.mark.parametrize("chunk_nnz", [64, 128, 2048])
-def test_cg_edge_cases_and_long_rows(ra, golden, chunk_nnz, lock_step):
+def test_cg_edge_cases_and_long_rows(ra, golden, chunk_nnz, form):
     """Empty rows (exactly 0), single-entry rows, one long row cut into chunks: the chunked sum is
     within rounding of the whole-row sum, and with enough steps CG lands on the reference's exact
     golden solution."""
@@ -114,10 +117,10 @@ def test_cg_edge_cases_and_long_rows(ra, golden, chunk_nnz, lock_step):
     ptr, ind, dat, shape = _csr(g)
     K = g["Y0"].shape[1]
     ref3 = als_ref.half_sweep_cg(ptr, ind, dat, g["Y0"], g["X0"], 0.01, 40.0, 3)
-    X3, _ = _sweep_cg(ra, ptr, ind, dat, shape, g["Y0"], g["X0"], 0.01, 40.0, 3, chunk_nnz=chunk_nnz, lock_step=lock_step)
+    X3, _ = _sweep_cg(ra, ptr, ind, dat, shape, g["Y0"], g["X0"], 0.01, 40.0, 3, chunk_nnz=chunk_nnz, form=form)
     assert _rel(X3, ref3) < 2e-4
     assert np.all(X3[0] == 0) and np.all(X3[-1] == 0)
-    Xn, _ = _sweep_cg(ra, ptr, ind, dat, shape, g["Y0"], g["X0"], 0.01, 40.0, 3 * K, chunk_nnz=chunk_nnz, lock_step=lock_step)
+    Xn, _ = _sweep_cg(ra, ptr, ind, dat, shape, g["Y0"], g["X0"], 0.01, 40.0, 3 * K, chunk_nnz=chunk_nnz, form=form)
     assert _rel(Xn, g["Xnew"]) < 1e-4
 
 
@@ -131,24 +134,27 @@ def test_cg_converges_to_golden_exact(ra, golden, K):
     assert _rel(X1, g[tag + "_X1"]) < 1e-4
 
 
-@pytest.mark.parametrize("f", [96, 192])
-def test_cg_row_ids_and_shards(ra, f):
+@pytest.mark.parametrize("f,form", [(96, "auto"), (192, "matrix"), (192, "auto"), (256, "matrix")])
+def test_cg_row_ids_and_shards(ra, f, form):
     """row_ids route CSR rows to arbitrary factor rows (others untouched); two row shards swept
-    separately equal the whole sweep bit for bit (f = 96: in-register form, 192: lock step)."""
+    separately equal the whole sweep bit for bit; long rows (chunk_nnz = 256) included."""
     rng = np.random.default_rng(42)
     N, M = 1500, 2000
     ptr, ind, dat = _random_csr(rng, N, M, 25, 1900)
     Y0 = rng.normal(0, 0.1, size=(M, f)).astype(np.float32); X0 = rng.normal(0, 0.1, size=(N, f)).astype(np.float32)
-    whole, _ = _sweep_cg(ra, ptr, ind, dat, (N, M), Y0, X0, 0.01, 40.0, 3, chunk_nnz=256)
+    whole, _ = _sweep_cg(ra, ptr, ind, dat, (N, M), Y0, X0, 0.01, 40.0, 3, chunk_nnz=256, form=form)
+    ref = als_ref.half_sweep_cg(ptr, ind, dat, Y0, X0, 0.01, 40.0, 3)
+    assert _rel(whole, ref) < 2e-4
     cut = 611
-    a, _ = _sweep_cg(ra, ptr[: cut + 1], ind[: ptr[cut]], dat[: ptr[cut]], (cut, M), Y0, X0[:cut], 0.01, 40.0, 3, chunk_nnz=256)
+    a, _ = _sweep_cg(ra, ptr[: cut + 1], ind[: ptr[cut]], dat[: ptr[cut]], (cut, M), Y0, X0[:cut], 0.01, 40.0, 3, chunk_nnz=256,
+                     form=form)
     b, _ = _sweep_cg(ra, ptr[cut:] - ptr[cut], ind[ptr[cut]:], dat[ptr[cut]:], (N - cut, M), Y0, X0[cut:], 0.01, 40.0, 3,
-                     chunk_nnz=256)
+                     chunk_nnz=256, form=form)
     assert np.array_equal(np.vstack([a, b]), whole)
     ids = rng.permutation(N + 7)[:N]
     Xbig = rng.normal(0, 0.1, size=(N + 7, f)).astype(np.float32)
     Xbig[ids] = X0
-    out, _ = _sweep_cg(ra, ptr, ind, dat, (N, M), Y0, Xbig, 0.01, 40.0, 3, chunk_nnz=256, row_ids=ids)
+    out, _ = _sweep_cg(ra, ptr, ind, dat, (N, M), Y0, Xbig, 0.01, 40.0, 3, chunk_nnz=256, row_ids=ids, form=form)
     assert np.array_equal(out[ids], whole)
     rest = np.setdiff1d(np.arange(N + 7), ids)
     assert np.array_equal(out[rest], Xbig[rest].astype(np.float64))
