@@ -99,7 +99,7 @@ int32_t als_plan_fill(const int64_t *rowptr_host, int64_t n_rows, int32_t chunk_
  * gram_out   [device] f*f floats, row major: Y^T Y (no lambda), exactly symmetric.
  * tiles_out  [device] als_gram_tiles_bytes(f) bytes: Y^T Y + lamb*I in the register-tile
  *            order the half-sweep kernel consumes (opaque to the caller).
- * The sum over rows is a fixed three-level tree (256-row chunks, 256-chunk groups, then
+ * The sum over rows is a fixed three-level tree (256-row chunks, 8 runs of 32 chunks per 65 536 rows, then
  * the groups in order), so a Gram assembled from als_gram_partials_f32 calls on several
  * devices equals the single-device one bit for bit.
  * f > ALS_MAX_FACTORS_EXACT: the same tree over 4096-row chunks of 64 x 64 blocks; tiles_out

@@ -794,17 +794,33 @@ __global__ __launch_bounds__(64) void gram_chunk_kernel(const float *__restrict_
         for (int r = 0; r < 4; ++r) P[(t * 4 + r) * 64 + lane] = acc[t][r];
 }
 
-// out[g][e] = in[g*group][e] + in[g*group+1][e] + ... (in order), e < elems
-__global__ void sum_groups_kernel(const float *__restrict__ in, const int64_t n_in, const int group,
-                                  const int elems, float *__restrict__ out) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= elems) return;
+// out[g][e] = sum of in[g*group .. g*group+group)[e], e < elems, as a fixed two-level tree: the
+// group is cut into SUBS runs of group/SUBS consecutive partials, each run is summed in order by one
+// thread (threadIdx.y), the run sums are added in run order.  blockDim = (64, SUBS).
+constexpr int SUM_SUBS = 8;
+__global__ __launch_bounds__(64 * SUM_SUBS) void sum_groups_kernel(const float *__restrict__ in, const int64_t n_in,
+                                                                   const int group, const int elems,
+                                                                   float *__restrict__ out) {
+    __shared__ float part[SUM_SUBS][64];
+    const int e = blockIdx.x * 64 + threadIdx.x;
     const int64_t g = blockIdx.y;
-    const int64_t first = g * group;
-    const int64_t last = min(n_in, first + group);
-    float acc = in[first * elems + e];
-    for (int64_t i = first + 1; i < last; ++i) acc += in[i * elems + e];
-    out[g * elems + e] = acc;
+    const int run = group / SUM_SUBS;
+    const int64_t first = g * group + (int64_t)threadIdx.y * run;
+    const int64_t last = min(n_in, first + run);
+    float acc = 0.f;
+    if (e < elems && first < last) {
+        acc = in[first * elems + e];
+        for (int64_t i = first + 1; i < last; ++i) acc += in[i * elems + e];
+    }
+    part[threadIdx.y][threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.y == 0 && e < elems) {
+        float t = part[0][threadIdx.x];
+        const int64_t n_here = min(n_in - g * group, (int64_t)group);      // partials in this group (>= 1)
+        for (int k = 1; k < SUM_SUBS; ++k)
+            if ((int64_t)k * run < n_here) t += part[k][threadIdx.x];
+        out[g * elems + e] = t;
+    }
 }
 
 // Sums the second-level partials in order, then writes the row-major Gram and the tile-order
@@ -892,8 +908,9 @@ static int32_t gram_partials_impl(const float *Y, int64_t row_begin, int64_t row
         hipLaunchKernelGGL((gram_chunk_kernel<VW, false, false>), grid, block, 0, st, Y, row_begin, row_end, ldy, f, chunks);
     ALS_HIP_CHECK(hipGetLastError());
     const int elems = G::TQ * 64;
-    hipLaunchKernelGGL(sum_groups_kernel, dim3((elems + 255) / 256, (unsigned)n_super), dim3(256), 0, st, chunks, n_chunks,
-                       ALS_GRAM_SUPER_ROWS / ALS_GRAM_CHUNK_ROWS, elems, super_out);
+    static_assert((ALS_GRAM_SUPER_ROWS / ALS_GRAM_CHUNK_ROWS) % SUM_SUBS == 0, "runs must tile a group");
+    hipLaunchKernelGGL(sum_groups_kernel, dim3((elems + 63) / 64, (unsigned)n_super), dim3(64, SUM_SUBS), 0, st, chunks,
+                       n_chunks, ALS_GRAM_SUPER_ROWS / ALS_GRAM_CHUNK_ROWS, elems, super_out);
     ALS_HIP_CHECK(hipGetLastError());
     return ALS_OK;
 }
