@@ -162,7 +162,10 @@ def main():
     if wl.get("solver") and args.solver == "cholesky" and f > 128:
         args.solver = wl["solver"]
     csr_u = ops.DeviceCSR(U[0], U[1], U[2], (ub[rank + 1] - ub[rank], M), dev)
-    csr_i = ops.DeviceCSR(Ut[0], Ut[1], Ut[2], (ib[rank + 1] - ib[rank], N), dev)
+    # with N user blocks an item row is N times longer: longer chunks keep the partial-sum traffic of the
+    # split rows (11 KB per chunk at f=64) small against the gather
+    csr_i = ops.DeviceCSR(Ut[0], Ut[1], Ut[2], (ib[rank + 1] - ib[rank], N), dev,
+                          chunk_nnz=2048 * (1 if world == 1 else 4))
     eng = ALSEngine(csr_u, csr_i, X, Y, wl["lamb"], wl["alpha"], ub, ib, group, solver=args.solver,
                     cg_steps=args.cg_steps)
     cg = args.solver == "cg"
