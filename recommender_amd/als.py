@@ -128,9 +128,15 @@ def _all_gather_rows(T, bounds, rank, group):
 
 
 def _chunk_cuts(n, parts):
-    """Boundaries of `parts` near-equal row chunks of a shard of n rows (every rank can compute
-    every other rank's cuts from the shard boundaries alone)."""
-    return [(n * c) // parts for c in range(parts + 1)]
+    """Boundaries of `parts` row chunks of a shard of n rows, sizes in the ratio parts : parts-1 : ... : 1
+    (the exchange of the last chunk is the one no sweep hides, so it is the smallest).  Every rank can
+    compute every other rank's cuts from the shard boundaries alone."""
+    total = parts * (parts + 1) // 2
+    cuts, acc = [0], 0
+    for c in range(parts):
+        acc += parts - c
+        cuts.append((n * acc) // total)
+    return cuts
 
 
 # ----------------------------------------------------------------------------- engine
