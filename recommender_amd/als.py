@@ -9,8 +9,8 @@ Host-side mirror of the reference's algorithm layer, reclibwh/core/ALS.py:
 
 One process drives one GPU.  With torch.distributed initialised (backend "nccl" = RCCL on
 ROCm, "gloo" in CPU tests) every rank keeps full replicas of X and Y, sweeps its own
-contiguous shard of user rows (then item rows) and the shards are all-gathered after each
-half-sweep; the Gram is summed from fixed 65 536-row partials in row order on every rank, so
+contiguous shard of user rows (then item rows) and the shards are all-gathered (the user shard
+chunk by chunk, beside the sweep of the next chunk); the Gram is summed from fixed 65 536-row partials in row order on every rank, so
 factors are bit-identical to a single-GPU run for any world size.
 """
 import numpy as np
