@@ -1,0 +1,30 @@
+#!/bin/bash
+# Re-measures every row of the table in DESIGN.md section 6 on one MI355X (a few minutes in total).
+# usage: tools/reproduce.sh            results: gpurun_out/repro_<tag>.json, one bench.py line each
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+mkdir -p "$ROOT/gpurun_out"
+run() {   # tag, bench args...
+  local tag=$1; shift
+  timeout -k 10 600 python3 "$ROOT/bench.py" --no-cpu-baseline "$@" > "$ROOT/gpurun_out/repro_$tag.log" 2>&1 || { echo "$tag FAILED"; tail -5 "$ROOT/gpurun_out/repro_$tag.log"; return 1; }
+  grep "^{" "$ROOT/gpurun_out/repro_$tag.log" > "$ROOT/gpurun_out/repro_$tag.json"
+  python3 - "$tag" "$ROOT/gpurun_out/repro_$tag.json" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[2]).read())
+r = d["roofline"]
+print("%-22s %8.2f ms/iter  %.3g nnz/s  %5.0f GB/s algorithmic (%.2f of HBM peak)  %s" % (
+    sys.argv[1], d["ms_per_step"], d["value"], r["achieved"], r["frac"], r["launch_ms"]), flush=True)
+PY
+}
+run c2_f64_exact                                   && \
+run c2_f64_exact_fp32    --accumulate fp32         && \
+run c2_f64_cg            --solver cg               && \
+run c2_f128_exact        --factors 128 --steps 5   && \
+run c2_f128_exact_fp32   --factors 128 --steps 5 --accumulate fp32 && \
+run c2_f128_cg           --factors 128 --steps 5 --solver cg && \
+run c2_f128_cg_lockstep  --factors 128 --steps 5 --solver cg --cg-form lock_step && \
+run c2_f256_cg           --factors 256 --steps 5 --solver cg && \
+run c3shard_exact        --workload c3_shard_syn --steps 3 --warmup 1 && \
+run c3shard_cg           --workload c3_shard_syn --steps 3 --warmup 1 --solver cg && \
+run c4shard_cg           --workload c4_shard_syn --steps 2 --warmup 1 && \
+python3 "$ROOT/tools/bench_topk.py" && python3 "$ROOT/tools/bench_gram.py"
