@@ -76,3 +76,37 @@ def test_two_ranks_one_gpu_equal_single_process(tmp_path, balance):
             got = np.load(os.path.join(out, "w2_r%d_%s.npz" % (r, balance)))
             assert np.array_equal(got["X"], ref["X"]) and np.array_equal(got["Y"], ref["Y"])
             np.testing.assert_allclose(got["trace"], ref["trace"], rtol=1e-6)
+
+
+def _rccl_single_rank(rank, port):
+    """RCCL itself, with the one rank a one-GPU box allows: the collective calls of the engine (in-place
+    all-gather, list outputs that alias the input, a side stream, all_reduce, barrier) are accepted and
+    leave the data intact."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    g = torch.distributed.group.WORLD
+    from recommender_amd import als
+    T = torch.arange(40, dtype=torch.float32, device=dev).reshape(10, 4).clone(); ref = T.clone()
+    als._all_gather_row_blocks(T, [0], [10], 0, g)
+    als._all_gather_row_blocks(T, [3], [4], 0, g)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        als._all_gather_row_blocks(T, [2], [5], 0, g)
+        ev = side.record_event()
+    torch.cuda.current_stream().wait_event(ev)
+    d = torch.ones(2, dtype=torch.float64, device=dev)
+    torch.distributed.all_reduce(d, group=g)
+    torch.distributed.barrier()
+    torch.cuda.synchronize()
+    assert torch.equal(T, ref) and float(d.sum()) == 2.0
+    torch.distributed.destroy_process_group()
+
+
+def test_rccl_single_rank_collectives():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    mp.spawn(_rccl_single_rank, args=(_free_port(),), nprocs=1, join=True)
