@@ -69,13 +69,16 @@ int32_t als_get_accumulate_mode(void);
  * (reclibwh/data/iterators.py:160-193, reclibwh/utils/utils.py:142-173): instead of
  * padded [B, Lmax] batches the device walks raw CSR rows.  A row with more than
  * chunk_nnz stored entries is split into ceil(nnz/chunk_nnz) chunk items whose partial
- * sums are combined in chunk order; items are sorted longest first.
+ * sums are combined in chunk order; items are sorted longest first.  An item is 32 bytes.
  * ------------------------------------------------------------------------------------ */
 typedef struct {
     int32_t row;    /* row of the CSR handed to als_half_sweep_csr_f32                      */
     int32_t chunk;  /* -1: whole row, solved in place; >= 0: chunk index within a long row  */
     int32_t slot;   /* partial-sum slot for a chunk item, -1 otherwise                      */
-    int32_t reserved;
+    int32_t count;  /* stored entries of this item                                          */
+    int64_t begin;  /* index of its first entry in col/val (rowptr[row] + chunk*chunk_nnz): */
+                    /* the kernels start from the item alone, one dependent load less       */
+    int64_t reserved;
 } als_item_t;
 
 typedef struct {

@@ -328,11 +328,7 @@ __global__ __launch_bounds__(64) void cg_items_kernel(const CgParams p) {
     const int lane = threadIdx.x;
     const als_item_t it = p.items[blockIdx.x];
     const int row = it.row;
-    int64_t s = p.rowptr[row], e = p.rowptr[row + 1];
-    if (it.chunk >= 0) {
-        s += (int64_t)it.chunk * p.chunk_nnz;
-        e = min(e, s + (int64_t)p.chunk_nnz);
-    }
+    const int64_t s = it.begin, e = it.begin + it.count;
     float dv[VW], acc[VW];
     cg_load_direction<VW, VEC, MODE>(p, row, lane & 15, dv);
 #pragma unroll

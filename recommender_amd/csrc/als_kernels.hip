@@ -682,11 +682,7 @@ void sweep_items_kernel(const SweepParams p) {
     const int lane = threadIdx.x;
     const als_item_t it = p.items[blockIdx.x];
     const int row = it.row;
-    int64_t s = p.rowptr[row], e = p.rowptr[row + 1];
-    if (it.chunk >= 0) {
-        s += (int64_t)it.chunk * p.chunk_nnz;
-        e = min(e, s + (int64_t)p.chunk_nnz);
-    }
+    const int64_t s = it.begin, e = it.begin + it.count;
     f32x4 acc[G::NT];
     float bacc[VW];
 #pragma unroll
@@ -983,7 +979,7 @@ int32_t als_profile_tap_next_sweep(void *ev_begin, void *ev_end) {
     g_tap_end = (hipEvent_t)ev_end;
     return ALS_OK;
 }
-int32_t als_abi_version(void) { return 2; }
+int32_t als_abi_version(void) { return 3; }
 
 int32_t als_set_accumulate_mode(int32_t mode) {
     if (mode != ALS_ACCUMULATE_FP32 && mode != ALS_ACCUMULATE_BF16X3)
@@ -1035,7 +1031,10 @@ int32_t als_plan_fill(const int64_t *rowptr, int64_t n_rows, int32_t chunk_nnz, 
         if (nnz > chunk_nnz) {
             const int32_t c = (int32_t)ceil_div(nnz, chunk_nnz);
             long_rows[lpos++] = als_long_row_t{(int32_t)r, slot, c, 0};
-            for (int32_t k = 0; k < c; ++k) items[pos++] = als_item_t{(int32_t)r, k, slot++, 0};
+            for (int32_t k = 0; k < c; ++k) {
+                const int64_t b = rowptr[r] + (int64_t)k * chunk_nnz;
+                items[pos++] = als_item_t{(int32_t)r, k, slot++, (int32_t)std::min<int64_t>(chunk_nnz, rowptr[r + 1] - b), b, 0};
+            }
         } else {
             bucket[chunk_nnz - nnz + 1] += 1;  // key = chunk_nnz - nnz: longest rows first
         }
@@ -1043,7 +1042,7 @@ int32_t als_plan_fill(const int64_t *rowptr, int64_t n_rows, int32_t chunk_nnz, 
     for (int64_t k = 1; k < (int64_t)bucket.size(); ++k) bucket[k] += bucket[k - 1];
     for (int64_t r = 0; r < n_rows; ++r) {
         const int64_t nnz = rowptr[r + 1] - rowptr[r];
-        if (nnz <= chunk_nnz) items[pos + bucket[chunk_nnz - nnz]++] = als_item_t{(int32_t)r, -1, -1, 0};
+        if (nnz <= chunk_nnz) items[pos + bucket[chunk_nnz - nnz]++] = als_item_t{(int32_t)r, -1, -1, (int32_t)nnz, rowptr[r], 0};
     }
     return ALS_OK;
 }

@@ -62,7 +62,7 @@ def get_accumulate_mode():
 # ----------------------------------------------------------------------------- plan (host only)
 def build_plan(indptr, chunk_nnz=_lib.DEFAULT_CHUNK_NNZ):
     """Row schedule for a CSR row-pointer array (host numpy int64).  Returns
-    (items [n_items, 4] int32, long_rows [n_long, 4] int32, n_slots)."""
+    (items [n_items, 8] int32 - 32-byte als_item_t records -, long_rows [n_long, 4] int32, n_slots)."""
     indptr = np.ascontiguousarray(indptr, dtype=np.int64)
     n_rows = indptr.shape[0] - 1
     if n_rows < 0:
@@ -70,7 +70,7 @@ def build_plan(indptr, chunk_nnz=_lib.DEFAULT_CHUNK_NNZ):
     ni, nl, ns = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
     check(lib.als_plan_count(indptr.ctypes.data, n_rows, chunk_nnz, ctypes.byref(ni), ctypes.byref(nl),
                              ctypes.byref(ns)), "als_plan_count")
-    items = np.empty((ni.value, 4), dtype=np.int32)
+    items = np.empty((ni.value, 8), dtype=np.int32)
     long_rows = np.empty((max(nl.value, 1), 4), dtype=np.int32)
     check(lib.als_plan_fill(indptr.ctypes.data, n_rows, chunk_nnz, items.ctypes.data, long_rows.ctypes.data),
           "als_plan_fill")

@@ -53,6 +53,11 @@ def test_plan_covers_every_row_once(chunk):
         mine = chunks[chunks[:, 0] == r]
         assert mine[:, 1].tolist() == list(range(n)) and mine[:, 2].tolist() == list(range(first, first + n))
     assert len(items) == len(direct) + n_slots
+    # every item carries its own entry range: begin (int64 in words 4-5) and count (word 3)
+    begin = items[:, 4:6].copy().view(np.int64)[:, 0]
+    assert np.array_equal(begin[items[:, 1] < 0], ptr[direct[:, 0]]) and np.array_equal(direct[:, 3], lens[direct[:, 0]])
+    assert np.array_equal(begin[items[:, 1] >= 0], ptr[chunks[:, 0]] + chunks[:, 1].astype(np.int64) * chunk)
+    assert np.array_equal(chunks[:, 3], np.minimum(chunk, lens[chunks[:, 0]] - chunks[:, 1] * chunk))
 
 
 def test_init_factors_match_reference_streams(golden):
