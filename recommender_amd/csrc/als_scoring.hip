@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <type_traits>
 
 #include "als_hip.h"
 
@@ -150,6 +151,249 @@ __global__ __launch_bounds__(256) void scores_kernel(const float *__restrict__ X
                 }
             }
         }
+}
+
+// ----------------------------------------------------------------------------- scores on the bf16 pipe
+// The same scores with every operand cut into three bf16 pieces by truncation (x = hi + mid + lo
+// exactly, 3 x 8 mantissa bits) and the 6 piece products of relative size >= 2^-16 issued as
+// v_mfma_f32_16x16x32_bf16 (fp32 accumulate; the dropped products are at fp32 rounding).  Six of
+// these cost 96 matrix-pipe cycles per 16 x 16 x 32 block against 256 for the fp32 form.
+//   workgroup   4 waves x 32 users = 128 users; a wave keeps its users' fragments (KS k-steps of
+//               32, 3 pieces) in registers for the whole launch and walks a range of items
+//   stage       32 items: the workgroup loads them once (one row segment of 32 bytes per thread),
+//               splits them and writes the fragments to LDS in operand order - fragment
+//               (item tile, k-step, piece) is 64 consecutive 16-byte lane slots, so writes and reads
+//               are linear in the lane index; two stages, one barrier per stage
+//   grid        workgroup ids go round the 8 XCDs, so the ids are laid out for the workgroups that
+//               stream the same items (one per 128-user block) to sit on the same XCD and share its L2
+// A score depends only on its user row and item row (fixed k order), not on the tiling.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack_trunc(const float a, const float b) {   // two truncated bf16: a low, b high
+    return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+__device__ __forceinline__ float trunc_bf16(const float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+
+struct Frag3 {
+    u32x4 h, m, l;
+};
+// 8 consecutive k of one row -> the lane's operand fragment of each piece
+__device__ __forceinline__ Frag3 split8(const f32x4 &a, const f32x4 &b) {
+    Frag3 o;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float x0 = p < 2 ? a[2 * p] : b[2 * p - 4], x1 = p < 2 ? a[2 * p + 1] : b[2 * p - 3];
+        const float r0 = x0 - trunc_bf16(x0), r1 = x1 - trunc_bf16(x1);
+        const float l0 = r0 - trunc_bf16(r0), l1 = r1 - trunc_bf16(r1);
+        o.h[p] = pack_trunc(x0, x1);
+        o.m[p] = pack_trunc(r0, r1);
+        o.l[p] = pack_trunc(l0, l1);
+    }
+    return o;
+}
+__device__ __forceinline__ f32x4 mfma_bf16(const u32x4 &a, const u32x4 &b, const f32x4 &c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+constexpr int SB_USERS = 128;   // users per workgroup
+constexpr int SB_ITEMS = 32;    // items per stage
+
+template <int KS, bool FILTER>
+__global__ __launch_bounds__(256, 2) void scores_split_kernel(const float *__restrict__ X, const int64_t ldx,
+                                                             const int64_t *__restrict__ user_ids, const int64_t nu,
+                                                             const float *__restrict__ Y, const int64_t ldy,
+                                                             const int64_t M, const int f, float *__restrict__ S,
+                                                             const int64_t lds, const int64_t item_begin,
+                                                             const int64_t stages_per_chunk, const int64_t n_user_blocks,
+                                                             const CandArgs cand) {
+    constexpr int FRAGS = 2 * KS * 3;                  // fragments per stage
+    constexpr int PAIRS = 2 * KS * 64;                 // (item, 8 k) row segments per stage
+    constexpr int NP = (PAIRS + 255) / 256;            // per thread
+    __shared__ u32x4 stage[2][FRAGS * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, j = lane & 15;
+    const int64_t w = blockIdx.x, per_round = 8 * n_user_blocks;
+    const int64_t ub = (w % per_round) / 8, chunk = (w / per_round) * 8 + w % 8;
+    const int64_t n_stages = (M - item_begin + SB_ITEMS - 1) / SB_ITEMS;
+    const int64_t t0 = chunk * stages_per_chunk, t1 = min(t0 + stages_per_chunk, n_stages);
+    if (t0 >= t1) return;                              // the whole workgroup
+    const int64_t u0 = ub * SB_USERS + wave * 32;
+
+    u32x4 AH[2][KS], AM[2][KS], AL[2][KS];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int64_t u = min(u0 + 16 * a + j, nu - 1);              // clamped: results are masked below
+        const float *xrow = X + (user_ids ? user_ids[u] : u) * ldx;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const Frag3 fr = split8(load4<true>(xrow, 32 * s + 8 * g, f), load4<true>(xrow, 32 * s + 8 * g + 4, f));
+            AH[a][s] = fr.h; AM[a][s] = fr.m; AL[a][s] = fr.l;
+        }
+    }
+    float tau[2][4];
+    if constexpr (FILTER) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                tau[a][r] = cand.score[min(u0 + 16 * a + 4 * g + r, nu - 1) * cand.cap + cand.k - 1];
+    }
+
+    // issue: raw loads only (from offset 0 where the segment lies beyond f), so nothing waits for them
+    // before the stage's matrix work; commit zeroes what lies beyond f, splits and writes to LDS
+    // loads run two stages ahead of the matrix work (a stage lasts about a microsecond, less than a
+    // trip to HBM under load): register set `par` holds the rows of stage t + 2 while stage t is multiplied
+    f32x4 ya[2][NP], yb[2][NP];
+    auto issue = [&](auto set_c, const int64_t t) {
+        constexpr int set = decltype(set_c)::value;
+#pragma unroll
+        for (int n = 0; n < NP; ++n) {
+            const int p = tid + 256 * n;               // wave uniform validity: PAIRS is a multiple of 64
+            if (p < PAIRS) {
+                const int c = p >> 6, it = c / KS, s = c % KS, k0 = 32 * s + 8 * g;
+                const int64_t item = min(item_begin + t * SB_ITEMS + it * 16 + j, M - 1);
+                const float *yrow = Y + item * ldy;
+                ya[set][n] = *reinterpret_cast<const f32x4 *>(yrow + (k0 < f ? k0 : 0));
+                yb[set][n] = *reinterpret_cast<const f32x4 *>(yrow + (k0 + 4 < f ? k0 + 4 : 0));
+            }
+        }
+    };
+    auto commit = [&](auto set_c, const int buf) {
+        constexpr int set = decltype(set_c)::value;
+#pragma unroll
+        for (int n = 0; n < NP; ++n) {
+            const int p = tid + 256 * n;
+            if (p < PAIRS) {
+                const int k0 = 32 * ((p >> 6) % KS) + 8 * g;
+                const f32x4 zero{0.f, 0.f, 0.f, 0.f};
+                const Frag3 fr = split8(k0 < f ? ya[set][n] : zero, k0 + 4 < f ? yb[set][n] : zero);
+                u32x4 *dst = &stage[buf][(p >> 6) * 3 * 64 + lane];
+                dst[0] = fr.h; dst[64] = fr.m; dst[128] = fr.l;
+            }
+        }
+    };
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
+    issue(Set0{}, t0);
+    if (t0 + 1 < t1) issue(Set1{}, t0 + 1);
+    commit(Set0{}, 0);
+    __syncthreads();
+    // FILTER: a hit reserves its slot in the user's candidate row with an integer atomic, whose answer
+    // takes about as long as a stage.  The lane parks the hit and writes it after the next stage's
+    // products (or at the end); only a lane's second hit within one stage waits for the first one's slot.
+    bool pend = false;
+    float pend_sc = 0.f;
+    int32_t pend_item = 0, pend_pos = 0;
+    int64_t pend_row = 0;
+    auto flush = [&]() {
+        if (pend) {
+            if (pend_pos < cand.cap) {
+                cand.score[pend_row + pend_pos] = pend_sc;
+                cand.item[pend_row + pend_pos] = pend_item;
+            } else {
+                atomicAdd(cand.overflow, 1);
+            }
+            pend = false;
+        }
+    };
+    // one stage: stage t sits in LDS buffer `par`, the rows of stage t + 1 are in flight in set par ^ 1
+    auto step = [&](auto par_c, const int64_t t) {
+        constexpr int par = decltype(par_c)::value;
+        constexpr int buf = par;
+        using Mine = std::integral_constant<int, par>;
+        using Other = std::integral_constant<int, par ^ 1>;
+        if (t + 2 < t1) issue(Mine{}, t + 2);
+        f32x4 acc[2][2];                               // [item tile][user tile]
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) acc[it][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            u32x4 BH[2], BM[2], BL[2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const u32x4 *src = &stage[buf][(it * KS + s) * 3 * 64 + lane];
+                BH[it] = src[0]; BM[it] = src[64]; BL[it] = src[128];
+            }
+            // smallest products first; consecutive MFMAs go to different accumulators
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) acc[it][a] = mfma_bf16(AL[a][s], BH[it], acc[it][a]);
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) acc[it][a] = mfma_bf16(AH[a][s], BL[it], acc[it][a]);
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) acc[it][a] = mfma_bf16(AM[a][s], BM[it], acc[it][a]);
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) acc[it][a] = mfma_bf16(AM[a][s], BH[it], acc[it][a]);
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) acc[it][a] = mfma_bf16(AH[a][s], BM[it], acc[it][a]);
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) acc[it][a] = mfma_bf16(AH[a][s], BH[it], acc[it][a]);
+        }
+        // C layout: lane (g, j), register r holds (user 4g + r, item j) of each 16 x 16 tile
+        if constexpr (FILTER) {
+            flush();                 // last stage's hit: its slot number has arrived by now
+            bool any_hit = false;    // most stages of most waves hold no score above a threshold: one test for all 16
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) any_hit = any_hit || fmaxf(acc[0][a][r], acc[1][a][r]) > tau[a][r];
+            if (__any(any_hit)) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t u = u0 + 16 * a + 4 * g + r;
+                        if (u >= nu) continue;
+#pragma unroll
+                        for (int it = 0; it < 2; ++it) {
+                            const int64_t i = item_begin + t * SB_ITEMS + it * 16 + j;
+                            const float sc = acc[it][a][r];
+                            if (i < M && sc > tau[a][r] && !excluded_item(cand, u, (int)i)) {
+                                flush();             // only a lane's second hit within one stage waits here
+                                pend = true;
+                                pend_pos = atomicAdd(&cand.count[u], 1);      // integer: which slot, not what value
+                                pend_sc = sc; pend_item = (int32_t)i; pend_row = u * cand.cap;
+                            }
+                        }
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t u = u0 + 16 * a + 4 * g + r;
+                    if (u >= nu) continue;
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        const int64_t i = item_begin + t * SB_ITEMS + it * 16 + j;
+                        if (i < M) S[u * lds + i] = acc[it][a][r];
+                    }
+                }
+        }
+        if (t + 1 < t1) commit(Other{}, buf ^ 1);
+        __syncthreads();
+    };
+    for (int64_t t = t0; t < t1; t += 2) {
+        step(Set0{}, t);
+        if (t + 1 < t1) step(Set1{}, t + 1);
+    }
+    if constexpr (FILTER) flush();
 }
 
 // ----------------------------------------------------------------------------- top-k
@@ -378,6 +622,34 @@ __global__ __launch_bounds__(64) void normalize_rows_kernel(const float *__restr
 
 }  // namespace
 
+// Launches the bf16-split score kernel if the operands allow it (16-byte vectors, f <= 128).
+// Returns false if they do not; the fp32 kernel then takes the call.
+template <bool FILTER>
+static bool launch_scores_split(const float *X, int64_t ldx, const int64_t *user_ids, int64_t nu, const float *Y,
+                                int64_t ldy, int64_t M, int32_t f, float *S, int64_t lds, int64_t item_begin,
+                                const CandArgs &cand, hipStream_t st) {
+    const bool vec = (f % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && ((uintptr_t)X % 16 == 0) &&
+                     ((uintptr_t)Y % 16 == 0);
+    if (!vec || f > 128 || M <= item_begin) return false;
+    const int64_t n_stages = (M - item_begin + SB_ITEMS - 1) / SB_ITEMS;
+    const int64_t nub = (nu + SB_USERS - 1) / SB_USERS;
+    // enough workgroups to fill the chip a few times over, at least 16 stages each (a workgroup
+    // first loads and splits its 128 user rows); the chunk count is a multiple of the 8 XCDs
+    int64_t n_chunks = std::max<int64_t>(8, (4096 / nub + 7) / 8 * 8);
+    n_chunks = std::min(n_chunks, ((n_stages + 15) / 16 + 7) / 8 * 8);
+    const int64_t per_chunk = (n_stages + n_chunks - 1) / n_chunks;
+    if (n_chunks * nub > 0x7fffffffLL) return false;
+    const dim3 grid((unsigned)(n_chunks * nub)), block(256);
+    const int ks = (f + 31) / 32;
+#define ALS_SCORES_SPLIT_CASE(n)                                                                                       \
+    if (ks == n)                                                                                                       \
+        hipLaunchKernelGGL((scores_split_kernel<n, FILTER>), grid, block, 0, st, X, ldx, user_ids, nu, Y, ldy, M, f, S, lds, \
+                           item_begin, per_chunk, nub, cand);
+    ALS_SCORES_SPLIT_CASE(1) ALS_SCORES_SPLIT_CASE(2) ALS_SCORES_SPLIT_CASE(3) ALS_SCORES_SPLIT_CASE(4)
+#undef ALS_SCORES_SPLIT_CASE
+    return true;
+}
+
 extern "C" {
 
 int32_t als_scores_f32(const float *X, int64_t ldx, const int64_t *user_ids, int64_t nu, const float *Y, int64_t ldy,
@@ -386,12 +658,16 @@ int32_t als_scores_f32(const float *X, int64_t ldx, const int64_t *user_ids, int
     if (nu < 1 || M < 1 || f < 1 || ldx < f || ldy < f || lds < M)
         return als_fail_(ALS_ERR_INVALID_ARG, "als_scores_f32: bad sizes (nu=%lld M=%lld f=%d)", (long long)nu,
                          (long long)M, f);
+    hipStream_t st = (hipStream_t)stream;
+    const CandArgs none{};
+    if (launch_scores_split<false>(X, ldx, user_ids, nu, Y, ldy, M, f, scores, lds, 0, none, st)) {
+        ALS_HIP_CHECK2(hipGetLastError());
+        return ALS_OK;
+    }
     const dim3 grid((unsigned)((M + 255) / 256), (unsigned)((nu + 63) / 64)), block(256);
     if (grid.y > 65535) return als_fail_(ALS_ERR_UNSUPPORTED, "als_scores_f32: more than 65535*64 users per call");
     const bool vec = (f % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && ((uintptr_t)X % 16 == 0) &&
                      ((uintptr_t)Y % 16 == 0);
-    hipStream_t st = (hipStream_t)stream;
-    const CandArgs none{};
     if (vec)
         hipLaunchKernelGGL((scores_kernel<true, false>), grid, block, 0, st, X, ldx, user_ids, nu, Y, ldy, M, f, scores, lds,
                            (int64_t)0, none);
@@ -460,7 +736,8 @@ int32_t als_recommend_topk_f32(const float *X, int64_t ldx, const int64_t *user_
     const bool vec = (f % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && ((uintptr_t)X % 16 == 0) &&
                      ((uintptr_t)Y % 16 == 0);
     const dim3 grid((unsigned)((M - S + 255) / 256), (unsigned)((nu + 63) / 64)), block(256);
-    if (vec)
+    if (launch_scores_split<true>(X, ldx, user_ids, nu, Y, ldy, M, f, nullptr, 0, S, c, st)) {
+    } else if (vec)
         hipLaunchKernelGGL((scores_kernel<true, true>), grid, block, 0, st, X, ldx, user_ids, nu, Y, ldy, M, f, nullptr,
                            (int64_t)0, S, c);
     else
