@@ -203,6 +203,11 @@ int32_t als_half_sweep_cg_f32(const int64_t *rowptr, const int32_t *col, const f
  *
  * als_scores_f32        scores[u][i] = <X[user_ids[u]], Y[i]> for u < nu, i < M (user_ids NULL:
  *                       rows 0..nu-1 of X).  scores is [nu, lds] row major, lds >= M.
+ *                       f <= 128 with 16-byte aligned rows (f, ldx, ldy multiples of 4): every
+ *                       operand is cut exactly into three bf16 pieces and the 6 largest piece
+ *                       products are accumulated in float32 on the matrix cores (error per
+ *                       product at float32 rounding); otherwise float32 products.  Either way a
+ *                       score depends only on its two rows, never on the launch shape.
  * als_topk_rows_f32     per row of `scores`, the k largest entries in descending order, ties by
  *                       ascending column (the reference does a full numpy argsort of every row,
  *                       RecAlgos.py:32; its consumers keep the first 200).  If ex_rowptr/ex_col
@@ -221,11 +226,13 @@ int32_t als_topk_rows_f32(float *scores, int64_t lds, int64_t n_rows, int64_t M,
                           const int32_t *ex_col, int32_t k, int32_t *idx_out, float *score_out, void *stream);
 /* Fused top-k - the whole of SimpleMFRecAlgo.recommend (RecAlgos.py:20-32) followed by the
  * "drop rated items, keep the best" filter of RecommenderService.py:16-29, without materialising
- * the [nu, M] score matrix: the first S items (S >= 65 536) are scored and selected exactly as by
- * als_scores_f32 + als_topk_rows_f32; their k-th best score is the user's threshold; the
- * remaining items are scored tile by tile on the matrix cores and only scores above the
- * threshold leave the registers (to a candidate list of 8192 slots per user); the candidates are
- * then ordered (score descending, ties by ascending item id).  Same result as the two-call path.
+ * the [nu, M] score matrix: the first S items (S = max(16 384, 16 k)) are scored and selected
+ * exactly as by als_scores_f32 + als_topk_rows_f32; their k-th best score is the user's
+ * threshold; the remaining items are scored tile by tile on the matrix cores, in ranges
+ * [S, 4S), [4S, 16S), ..., and only scores above the threshold leave the registers (to a candidate
+ * list of 8192 slots per user); after each range the candidates are ordered (score descending,
+ * ties by ascending item id) and cut back to k, which tightens the threshold for the next range.
+ * Same result as the two-call path.
  * ex_rowptr/ex_col: optional CSR (nu rows, sorted columns) of items to exclude per user.
  * overflow_out [device] one int32: number of candidates that did not fit a user's list; if it is
  * not 0 the outputs are not valid and the caller must use the two-call path for these users.

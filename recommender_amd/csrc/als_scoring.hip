@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void scores_split_kernel(const float *__res
     // issue: raw loads only (from offset 0 where the segment lies beyond f), so nothing waits for them
     // before the stage's matrix work; commit zeroes what lies beyond f, splits and writes to LDS
     // loads run two stages ahead of the matrix work (a stage lasts about a microsecond, less than a
-    // trip to HBM under load): register set `par` holds the rows of stage t + 2 while stage t is multiplied
+    // trip to HBM under load): a register set is refilled as soon as its rows have gone to LDS
     f32x4 ya[2][NP], yb[2][NP];
     auto issue = [&](auto set_c, const int64_t t) {
         constexpr int set = decltype(set_c)::value;
@@ -279,6 +279,7 @@ __global__ __launch_bounds__(256, 2) void scores_split_kernel(const float *__res
     issue(Set0{}, t0);
     if (t0 + 1 < t1) issue(Set1{}, t0 + 1);
     commit(Set0{}, 0);
+    if (t0 + 2 < t1) issue(Set0{}, t0 + 2);
     __syncthreads();
     // FILTER: a hit reserves its slot in the user's candidate row with an integer atomic, whose answer
     // takes about as long as a stage.  The lane parks the hit and writes it after the next stage's
@@ -298,13 +299,11 @@ __global__ __launch_bounds__(256, 2) void scores_split_kernel(const float *__res
             pend = false;
         }
     };
-    // one stage: stage t sits in LDS buffer `par`, the rows of stage t + 1 are in flight in set par ^ 1
+    // one stage: stage t sits in LDS buffer `par`; the rows of stage t + 1 are in set par ^ 1, those of t + 2 in set par
     auto step = [&](auto par_c, const int64_t t) {
         constexpr int par = decltype(par_c)::value;
         constexpr int buf = par;
-        using Mine = std::integral_constant<int, par>;
         using Other = std::integral_constant<int, par ^ 1>;
-        if (t + 2 < t1) issue(Mine{}, t + 2);
         f32x4 acc[2][2];                               // [item tile][user tile]
 #pragma unroll
         for (int it = 0; it < 2; ++it)
@@ -387,6 +386,7 @@ __global__ __launch_bounds__(256, 2) void scores_split_kernel(const float *__res
                 }
         }
         if (t + 1 < t1) commit(Other{}, buf ^ 1);
+        if (t + 3 < t1) issue(Other{}, t + 3);       // into the registers commit has just read
         __syncthreads();
     };
     for (int64_t t = t0; t < t1; t += 2) {
@@ -542,9 +542,10 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(float *__restrict__ S, c
 // (score descending, item id ascending - the order does not depend on the order of arrival)
 // in LDS and writes the first k.
 constexpr int CAND_CAP = 8192;
-__global__ __launch_bounds__(256) void select_candidates_kernel(const float *__restrict__ cscore,
-                                                               const int32_t *__restrict__ citem,
-                                                               const int32_t *__restrict__ count, const int cap,
+// idx_out == nullptr: the first k go back to the head of the candidate row and the row's count
+// becomes k (the row's threshold, slot k-1, tightens for the items still to come).
+__global__ __launch_bounds__(256) void select_candidates_kernel(float *__restrict__ cscore, int32_t *__restrict__ citem,
+                                                               int32_t *__restrict__ count, const int cap,
                                                                const int k, int32_t *__restrict__ idx_out,
                                                                float *__restrict__ score_out) {
     __shared__ uint32_t key[CAND_CAP];
@@ -577,9 +578,17 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(const float *__r
             __syncthreads();
         }
     }
-    for (int q = tid; q < k; q += 256) {
-        idx_out[row * k + q] = item[q];
-        score_out[row * k + q] = key_to_float(key[q]);
+    if (idx_out) {
+        for (int q = tid; q < k; q += 256) {
+            idx_out[row * k + q] = item[q];
+            score_out[row * k + q] = key_to_float(key[q]);
+        }
+    } else {
+        for (int q = tid; q < k; q += 256) {
+            citem[row * cap + q] = item[q];
+            cscore[row * cap + q] = key_to_float(key[q]);
+        }
+        if (tid == 0) count[row] = k;
     }
 }
 
@@ -679,9 +688,13 @@ int32_t als_scores_f32(const float *X, int64_t ldx, const int64_t *user_ids, int
 }
 
 // ----------------------------------------------------------------------------- fused top-k
+// The fused top-k walks the items in ranges [S, 4S), [4S, 16S), ...: the first S items are scored
+// into memory and selected exactly; every later range is filtered against the user's k-th best so
+// far and the candidate rows are cut back to their k best between ranges.  A range is expected to
+// add k * (range length) / (items before it) = 3k candidates per user, far below CAND_CAP.
+constexpr int FUSED_RANGE_GROWTH = 4;
 static int64_t fused_subset_items(int64_t M, int32_t k) {
-    // enough early items that about k*M/S <= CAND_CAP/4 later items are expected above the threshold
-    int64_t s = std::max<int64_t>(65536, ((int64_t)k * M / (CAND_CAP / 4) + 255) / 256 * 256);
+    const int64_t s = std::max<int64_t>(16384, ((int64_t)k * 16 + 255) / 256 * 256);
     return std::min(M, s);
 }
 static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
@@ -732,22 +745,28 @@ int32_t als_recommend_topk_f32(const float *X, int64_t ldx, const int64_t *user_
     hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)nu), dim3(256), 0, st, sub, S, S, ex_rowptr, ex_col, k, c.item,
                        c.score, (int64_t)CAND_CAP);
     ALS_HIP_CHECK2(hipGetLastError());
-    // 2. the later items: score tiles are compared with the user's threshold in registers, never stored
+    // 2. the later items, range by range: score tiles are compared with the user's threshold in
+    //    registers, never stored; then each user's candidates are ordered and cut back to k
     const bool vec = (f % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && ((uintptr_t)X % 16 == 0) &&
                      ((uintptr_t)Y % 16 == 0);
-    const dim3 grid((unsigned)((M - S + 255) / 256), (unsigned)((nu + 63) / 64)), block(256);
-    if (launch_scores_split<true>(X, ldx, user_ids, nu, Y, ldy, M, f, nullptr, 0, S, c, st)) {
-    } else if (vec)
-        hipLaunchKernelGGL((scores_kernel<true, true>), grid, block, 0, st, X, ldx, user_ids, nu, Y, ldy, M, f, nullptr,
-                           (int64_t)0, S, c);
-    else
-        hipLaunchKernelGGL((scores_kernel<false, true>), grid, block, 0, st, X, ldx, user_ids, nu, Y, ldy, M, f, nullptr,
-                           (int64_t)0, S, c);
-    ALS_HIP_CHECK2(hipGetLastError());
-    // 3. order each user's candidates and keep k
-    hipLaunchKernelGGL(select_candidates_kernel, dim3((unsigned)nu), dim3(256), 0, st, c.score, c.item, c.count, CAND_CAP,
-                       k, idx_out, score_out);
-    ALS_HIP_CHECK2(hipGetLastError());
+    for (int64_t begin = S; begin < M;) {
+        int64_t end = (begin > M / FUSED_RANGE_GROWTH) ? M : begin * FUSED_RANGE_GROWTH;
+        if (M - end < end / FUSED_RANGE_GROWTH) end = M;      // no short last range
+        const dim3 grid((unsigned)((end - begin + 255) / 256), (unsigned)((nu + 63) / 64)), block(256);
+        if (launch_scores_split<true>(X, ldx, user_ids, nu, Y, ldy, end, f, nullptr, 0, begin, c, st)) {
+        } else if (vec)
+            hipLaunchKernelGGL((scores_kernel<true, true>), grid, block, 0, st, X, ldx, user_ids, nu, Y, ldy, end, f, nullptr,
+                               (int64_t)0, begin, c);
+        else
+            hipLaunchKernelGGL((scores_kernel<false, true>), grid, block, 0, st, X, ldx, user_ids, nu, Y, ldy, end, f, nullptr,
+                               (int64_t)0, begin, c);
+        ALS_HIP_CHECK2(hipGetLastError());
+        const bool last = end == M;
+        hipLaunchKernelGGL(select_candidates_kernel, dim3((unsigned)nu), dim3(256), 0, st, c.score, c.item, c.count, CAND_CAP,
+                           k, last ? idx_out : nullptr, last ? score_out : nullptr);
+        ALS_HIP_CHECK2(hipGetLastError());
+        begin = end;
+    }
     return ALS_OK;
 }
 

@@ -231,10 +231,11 @@ def _two_call(ra, X, Y, users, k, ex):
     return ra.ops.recommend_topk(X, Y, users, k, exclude_csr=ex, fused=False)
 
 
-@pytest.mark.parametrize("f,k", [(32, 100), (20, 7), (64, 1024)])
+@pytest.mark.parametrize("f,k", [(32, 100), (20, 7), (64, 1024), (21, 10), (128, 100)])
 def test_fused_topk_equals_two_call_path(ra, f, k):
-    """The fused top-k (threshold from the first 65 536 items, the rest filtered in the score
-    kernel's registers) returns exactly what scores + top-k on the materialised matrix returns:
+    """The fused top-k (threshold from the first 16 384 items, the rest filtered in the score
+    kernel's registers in two growing ranges, candidate rows cut back to k in between; f=21 takes
+    the element-wise fp32 kernel) returns exactly what scores + top-k on the materialised matrix returns:
     same items in the same order (ties by ascending id: factors are quantised so that equal
     scores abound), same score bits, with and without per-user exclusions."""
     rng = np.random.default_rng(f + k)
@@ -258,8 +259,8 @@ def test_fused_topk_equals_two_call_path(ra, f, k):
 
 
 def test_fused_topk_overflow_falls_back(ra):
-    """Adversarial item order: the first 65 536 items all score below the rest, so every later
-    item beats the threshold, the candidate lists overflow and the block is redone by the
+    """Adversarial item order: the first 65 536 items all score below the rest, so every item of
+    the last range beats the threshold, the candidate lists overflow and the block is redone by the
     two-call path - the result is still exact."""
     rng = np.random.default_rng(3)
     nu, M, f, k = 70, 100000, 16, 50
