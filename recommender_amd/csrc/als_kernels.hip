@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -49,7 +50,7 @@ namespace {
 // ----------------------------------------------------------------------------- errors
 thread_local char g_err[512] = "";
 thread_local hipEvent_t g_tap_begin = nullptr, g_tap_end = nullptr;
-int g_accumulate_mode = ALS_ACCUMULATE_BF16X3;
+std::atomic<int> g_accumulate_mode{ALS_ACCUMULATE_BF16X3};   // process wide; read once per launch
 
 int fail(int code, const char *fmt, ...) {
     va_list ap;

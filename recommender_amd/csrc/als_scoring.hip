@@ -206,6 +206,7 @@ __global__ __launch_bounds__(256, 2) void scores_split_kernel(const float *__res
                                                              const int64_t M, const int f, float *__restrict__ S,
                                                              const int64_t lds, const int64_t item_begin,
                                                              const int64_t stages_per_chunk, const int64_t n_user_blocks,
+                                                             const int chunks_per_round,
                                                              const CandArgs cand) {
     constexpr int FRAGS = 2 * KS * 3;                  // fragments per stage
     constexpr int PAIRS = 2 * KS * 64;                 // (item, 8 k) row segments per stage
@@ -214,8 +215,8 @@ __global__ __launch_bounds__(256, 2) void scores_split_kernel(const float *__res
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, j = lane & 15;
-    const int64_t w = blockIdx.x, per_round = 8 * n_user_blocks;
-    const int64_t ub = (w % per_round) / 8, chunk = (w / per_round) * 8 + w % 8;
+    const int64_t w = blockIdx.x, per_round = chunks_per_round * n_user_blocks;
+    const int64_t ub = (w % per_round) / chunks_per_round, chunk = (w / per_round) * chunks_per_round + w % chunks_per_round;
     const int64_t n_stages = (M - item_begin + SB_ITEMS - 1) / SB_ITEMS;
     const int64_t t0 = chunk * stages_per_chunk, t1 = min(t0 + stages_per_chunk, n_stages);
     if (t0 >= t1) return;                              // the whole workgroup
@@ -644,8 +645,11 @@ static bool launch_scores_split(const float *X, int64_t ldx, const int64_t *user
     const int64_t nub = (nu + SB_USERS - 1) / SB_USERS;
     // enough workgroups to fill the chip a few times over, at least 16 stages each (a workgroup
     // first loads and splits its 128 user rows); the chunk count is a multiple of the 8 XCDs
+    // (8 consecutive workgroup ids = 8 different chunks); few items: one chunk, no XCD layout needed
     int64_t n_chunks = std::max<int64_t>(8, (4096 / nub + 7) / 8 * 8);
     n_chunks = std::min(n_chunks, ((n_stages + 15) / 16 + 7) / 8 * 8);
+    if (n_stages <= 16) n_chunks = 1;
+    const int cpr = n_chunks >= 8 ? 8 : 1;
     const int64_t per_chunk = (n_stages + n_chunks - 1) / n_chunks;
     if (n_chunks * nub > 0x7fffffffLL) return false;
     const dim3 grid((unsigned)(n_chunks * nub)), block(256);
@@ -653,7 +657,7 @@ static bool launch_scores_split(const float *X, int64_t ldx, const int64_t *user
 #define ALS_SCORES_SPLIT_CASE(n)                                                                                       \
     if (ks == n)                                                                                                       \
         hipLaunchKernelGGL((scores_split_kernel<n, FILTER>), grid, block, 0, st, X, ldx, user_ids, nu, Y, ldy, M, f, S, lds, \
-                           item_begin, per_chunk, nub, cand);
+                           item_begin, per_chunk, nub, cpr, cand);
     ALS_SCORES_SPLIT_CASE(1) ALS_SCORES_SPLIT_CASE(2) ALS_SCORES_SPLIT_CASE(3) ALS_SCORES_SPLIT_CASE(4)
 #undef ALS_SCORES_SPLIT_CASE
     return true;

@@ -422,12 +422,12 @@ def _block_exclusions(exclude_csr, users_host, device):
             if p[-1] else torch.zeros(1, dtype=torch.int32, device=device))
 
 
-def recommend_topk(X, Y, users, k, M=None, exclude_csr=None, block_users=1024, fused=True):
+def recommend_topk(X, Y, users, k, M=None, exclude_csr=None, block_users=4096, fused=True):
     """Top-k items for `users` (int64 device tensor), block_users users at a time.
     exclude_csr: optional (rowptr, col) HOST numpy CSR over ALL users (sorted columns) whose
     columns are filtered per user.  Returns (idx int32 [nu, k], scores [nu, k]).
 
-    fused=True: als_recommend_topk_f32 - only the first 65 536+ items of a block are materialised,
+    fused=True: als_recommend_topk_f32 - only the first 16 384+ items of a block are materialised,
     the rest is filtered in the score kernel's registers.  A block whose candidate lists overflow
     (reported by the library) is redone by the two-call path, as is everything when fused=False."""
     ldx = _factor_ld(X, "X"); ldy = _factor_ld(Y, "Y")
@@ -448,27 +448,27 @@ def recommend_topk(X, Y, users, k, M=None, exclude_csr=None, block_users=1024, f
     bu = min(block_users, max(nu, 1))
     buf = None
     blocks = [(s, min(nu, s + block_users)) for s in range(0, nu, block_users)]
-    exs = {}
     redo = list(range(len(blocks)))
     if fused and blocks:
         ws = torch.empty(lib.als_recommend_topk_workspace_bytes(bu, M, k), dtype=torch.uint8, device=X.device)
         overflow = torch.zeros(len(blocks), dtype=torch.int32, device=X.device)
         for b, (s, e) in enumerate(blocks):
             ex = _block_exclusions(exclude_csr, users_host[s:e], X.device) if exclude_csr is not None else None
-            exs[b] = ex
             with torch.cuda.device(X.device):
                 check(lib.als_recommend_topk_f32(_ptr(X), ldx, _ptr(users[s:e]), e - s, _ptr(Y), ldy, M, f, k,
                                                  _ptr(ex[0]) if ex else None, _ptr(ex[1]) if ex else None,
                                                  _ptr(idx[s:e]), _ptr(val[s:e]), _ptr(overflow[b:b + 1]), _ptr(ws),
                                                  ws.numel(), _stream()), "als_recommend_topk_f32")
         redo = torch.nonzero(overflow).flatten().cpu().tolist()       # one synchronisation for all blocks
+    # the materialised path works on row blocks whose score matrix stays below 4 GiB
+    rows_per = max(1, min(bu, (1 << 30) // M))
     for b in redo:
-        s, e = blocks[b]
-        ex = exs[b] if b in exs else (_block_exclusions(exclude_csr, users_host[s:e], X.device)
-                                      if exclude_csr is not None else None)
-        if buf is None:
-            buf = torch.empty((bu, M), dtype=torch.float32, device=X.device)
-        sc = scores(X, Y, users[s:e], M, out=buf)
-        i_, v_ = topk_rows(sc, k, ex)
-        idx[s:e] = i_; val[s:e] = v_
+        for s in range(blocks[b][0], blocks[b][1], rows_per):
+            e = min(blocks[b][1], s + rows_per)
+            ex = _block_exclusions(exclude_csr, users_host[s:e], X.device) if exclude_csr is not None else None
+            if buf is None:
+                buf = torch.empty((rows_per, M), dtype=torch.float32, device=X.device)
+            sc = scores(X, Y, users[s:e], M, out=buf)
+            i_, v_ = topk_rows(sc, k, ex)
+            idx[s:e] = i_; val[s:e] = v_
     return idx, val

@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--items", type=int, default=1000000)
     ap.add_argument("--factors", type=int, default=128)
     ap.add_argument("--k", type=int, default=100)
-    ap.add_argument("--block-users", type=int, default=1024)
+    ap.add_argument("--block-users", type=int, default=4096)
     a = ap.parse_args()
     g = torch.Generator(device="cuda"); g.manual_seed(1)
     X = torch.randn((a.users, a.factors), generator=g, device="cuda") / a.factors ** 0.5
@@ -32,11 +32,12 @@ def main():
     e[0].record()
     idx, val = ops.recommend_topk(X, Y, users, a.k, block_users=a.block_users)
     e[1].record()
-    buf = torch.empty((a.block_users, a.items), device="cuda")
+    rows = min(a.block_users, 1024)
+    buf = torch.empty((rows, a.items), device="cuda")
     torch.cuda.synchronize()
     e[2].record()
-    for s in range(0, a.users, a.block_users):
-        ops.scores(X, Y, users[s:s + a.block_users], a.items, out=buf)
+    for s in range(0, a.users, rows):
+        ops.scores(X, Y, users[s:s + rows], a.items, out=buf)
     e[3].record()
     torch.cuda.synchronize()
     total, gemm = e[0].elapsed_time(e[1]), e[2].elapsed_time(e[3])
