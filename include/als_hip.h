@@ -69,7 +69,9 @@ int32_t als_get_accumulate_mode(void);
  * (reclibwh/data/iterators.py:160-193, reclibwh/utils/utils.py:142-173): instead of
  * padded [B, Lmax] batches the device walks raw CSR rows.  A row with more than
  * chunk_nnz stored entries is split into ceil(nnz/chunk_nnz) chunk items whose partial
- * sums are combined in chunk order; items are sorted longest first.  An item is 32 bytes.
+ * sums are combined in chunk order; items are sorted longest first.  An item is 32 bytes and
+ * carries its own entry range, so a plan belongs to the row pointer it was built from: the
+ * sweeps trust it (an item whose range lies outside col/val is an out-of-bounds read).
  * ------------------------------------------------------------------------------------ */
 typedef struct {
     int32_t row;    /* row of the CSR handed to als_half_sweep_csr_f32                      */
