@@ -215,21 +215,45 @@ __device__ __forceinline__ float trunc_bf16(const float x) { return __uint_as_fl
 
 // Pieces of the GS k-steps of one stage into fragment registers [QB/2, QB/2 + GS/2); also bacc.
 // st.w holds sqrt(alpha r) here.
+// The elementwise work runs on pairs of adjacent factor indices (v_pk_mul_f32 / v_pk_add_f32 /
+// v_pk_fma_f32: two float32 operations per instruction, bit-identical to the scalar forms).
+__device__ __forceinline__ f32x2 trunc_bf16(const f32x2 x) { return f32x2{trunc_bf16(x.x), trunc_bf16(x.y)}; }
 template <int VW>
 __device__ __forceinline__ void split_stage(const Stage<VW> &st, const int QB, SplitOps<VW> &o, float (&bacc)[VW]) {
     constexpr int GS = StageGeo<VW>::GS;
+    static_assert(VW % 2 == 0, "pairs of factor indices");
+    if constexpr (VW < 8) {      // 3 waves per SIMD: the scalar form needs fewer registers there and is as fast
+#pragma unroll
+        for (int p = 0; p < GS / 2; ++p) {
+#pragma unroll
+            for (int t = 0; t < VW; ++t) {
+                const float x0 = st.w[2 * p] * st.v[2 * p][t], x1 = st.w[2 * p + 1] * st.v[2 * p + 1][t];
+                bacc[t] = fmaf(st.cw[2 * p], st.v[2 * p][t], bacc[t]);
+                bacc[t] = fmaf(st.cw[2 * p + 1], st.v[2 * p + 1][t], bacc[t]);
+                const float r0 = x0 - trunc_bf16(x0), r1 = x1 - trunc_bf16(x1);
+                const float l0 = r0 - trunc_bf16(r0), l1 = r1 - trunc_bf16(r1);
+                o.H[t][QB / 2 + p] = pack_trunc(x0, x1);
+                o.M[t][QB / 2 + p] = pack_trunc(r0, r1);
+                o.L[t][QB / 2 + p] = pack_trunc(l0, l1);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int p = 0; p < GS / 2; ++p) {
 #pragma unroll
-        for (int t = 0; t < VW; ++t) {
-            const float x0 = st.w[2 * p] * st.v[2 * p][t], x1 = st.w[2 * p + 1] * st.v[2 * p + 1][t];
-            bacc[t] = fmaf(st.cw[2 * p], st.v[2 * p][t], bacc[t]);
-            bacc[t] = fmaf(st.cw[2 * p + 1], st.v[2 * p + 1][t], bacc[t]);
-            const float r0 = x0 - trunc_bf16(x0), r1 = x1 - trunc_bf16(x1);
-            const float l0 = r0 - trunc_bf16(r0), l1 = r1 - trunc_bf16(r1);
-            o.H[t][QB / 2 + p] = pack_trunc(x0, x1);
-            o.M[t][QB / 2 + p] = pack_trunc(r0, r1);
-            o.L[t][QB / 2 + p] = pack_trunc(l0, l1);
+        for (int t = 0; t < VW; t += 2) {
+            const f32x2 v0{st.v[2 * p][t], st.v[2 * p][t + 1]}, v1{st.v[2 * p + 1][t], st.v[2 * p + 1][t + 1]};
+            const f32x2 x0 = v0 * st.w[2 * p], x1 = v1 * st.w[2 * p + 1];
+            f32x2 b{bacc[t], bacc[t + 1]};
+            b = __builtin_elementwise_fma(f32x2{st.cw[2 * p], st.cw[2 * p]}, v0, b);
+            b = __builtin_elementwise_fma(f32x2{st.cw[2 * p + 1], st.cw[2 * p + 1]}, v1, b);
+            bacc[t] = b.x; bacc[t + 1] = b.y;
+            const f32x2 r0 = x0 - trunc_bf16(x0), r1 = x1 - trunc_bf16(x1);
+            const f32x2 l0 = r0 - trunc_bf16(r0), l1 = r1 - trunc_bf16(r1);
+            o.H[t][QB / 2 + p] = pack_trunc(x0.x, x1.x); o.H[t + 1][QB / 2 + p] = pack_trunc(x0.y, x1.y);
+            o.M[t][QB / 2 + p] = pack_trunc(r0.x, r1.x); o.M[t + 1][QB / 2 + p] = pack_trunc(r0.y, r1.y);
+            o.L[t][QB / 2 + p] = pack_trunc(l0.x, l1.x); o.L[t + 1][QB / 2 + p] = pack_trunc(l0.y, l1.y);
         }
     }
 }
