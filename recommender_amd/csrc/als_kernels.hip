@@ -446,7 +446,7 @@ __device__ __forceinline__ f32x4 tile_x_v(const f32x4 &X, const float vcol) {
 // are these.  The compiler does not see inside an asm statement, so the DPP read hazard (a VGPR
 // written by a vector instruction may be read through DPP two wait states later at the earliest)
 // is handled here: the statements are volatile, hence stay in program order, and every register
-// is touched once per elimination step (8 statements apart); GUARD adds the wait states for the
+// is touched at most once per elimination step (4 to 8 statements apart); GUARD adds the wait states for the
 // one step whose source was last written by compiler-scheduled code.
 #define ALS_FMAC_BCAST_CASE(n)                                                                            \
     if constexpr (K == n) {                                                                               \
@@ -483,11 +483,18 @@ __device__ __forceinline__ void diag_step(f32x4 &D, f32x4 &N, const int c) {
             N[r] = fmaf(dpp_f<0x150 + K>(N[r]), nv, N[r]);
         }
     } else {
+        // register r holds rows r, 4+r, 8+r, 12+r.  Rows <= K of D are never read again (only the
+        // pivots are, and row K's is final), and column K of N is still zero below row K: registers
+        // that hold only such rows are left alone.
         float d0 = D[0], d1 = D[1], d2 = D[2], d3 = D[3], n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3];
-        fmac_bcast<K, K == 1>(d0, nv); fmac_bcast<K, K == 1>(d1, nv);
-        fmac_bcast<K, K == 1>(d2, nv); fmac_bcast<K, K == 1>(d3, nv);
-        fmac_bcast<K, K == 1>(n0, nv); fmac_bcast<K, K == 1>(n1, nv);
-        fmac_bcast<K, K == 1>(n2, nv); fmac_bcast<K, K == 1>(n3, nv);
+        if constexpr (K < 12) fmac_bcast<K, K == 1>(d0, nv);
+        if constexpr (K < 13) fmac_bcast<K, K == 1>(d1, nv);
+        if constexpr (K < 14) fmac_bcast<K, K == 1>(d2, nv);
+        if constexpr (K < 15) fmac_bcast<K, K == 1>(d3, nv);
+        fmac_bcast<K, K == 1>(n0, nv);
+        fmac_bcast<K, K == 1>(n1, nv);
+        if constexpr (K >= 2) fmac_bcast<K, K == 1>(n2, nv);
+        if constexpr (K >= 3) fmac_bcast<K, K == 1>(n3, nv);
         D = f32x4{d0, d1, d2, d3};
         N = f32x4{n0, n1, n2, n3};
     }
@@ -560,32 +567,31 @@ __device__ __forceinline__ bool blocked_solve(f32x4 (&T)[Geo<VW>::NT], float (&b
 template <int VW>
 __device__ __forceinline__ void sym_tiles_matvec(const f32x4 (&T)[Geo<VW>::NT], const float (&v)[VW], float (&y)[VW],
                                                  const int lane) {
-    f32x4 vrow[VW], orow[VW];
-    float ocol[VW];
+    // register pairs: two multiply-adds per v_pk_fma_f32
+    f32x4 vrow[VW];
+    f32x2 olo[VW], ohi[VW], ocol[VW];
 #pragma unroll
     for (int t = 0; t < VW; ++t) {
         vrow[t] = vec_col_to_row(v[t], lane);
-        orow[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        ocol[t] = 0.f;
+        olo[t] = ohi[t] = ocol[t] = f32x2{0.f, 0.f};
     }
 #pragma unroll
     for (int ib = 0; ib < VW; ++ib)
 #pragma unroll
         for (int jb = ib; jb < VW; ++jb) {
             const f32x4 &t = T[tile_index(ib, jb, VW)];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) orow[ib][r] = fmaf(t[r], v[jb], orow[ib][r]);         // (T v)[4g + r], before the lane sum
-            if (jb > ib) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ocol[jb] = fmaf(t[r], vrow[ib][r], ocol[jb]);     // (T^T v)[c], before the group sum
+            const f32x2 vj{v[jb], v[jb]};
+            olo[ib] = __builtin_elementwise_fma(t.lo, vj, olo[ib]);                  // (T v)[4g + r], before the lane sum
+            ohi[ib] = __builtin_elementwise_fma(t.hi, vj, ohi[ib]);
+            if (jb > ib) {                                                           // (T^T v)[c], before the group sum
+                ocol[jb] = __builtin_elementwise_fma(t.lo, vrow[ib].lo, ocol[jb]);
+                ocol[jb] = __builtin_elementwise_fma(t.hi, vrow[ib].hi, ocol[jb]);
             }
         }
 #pragma unroll
     for (int ib = 0; ib < VW; ++ib) {
-        f32x4 srow;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) srow[r] = row_sum16(orow[ib][r]);
-        y[ib] = vec_row_to_col(srow, lane) + grp_sum4(ocol[ib]);
+        const f32x4 srow{row_sum16(olo[ib].x), row_sum16(olo[ib].y), row_sum16(ohi[ib].x), row_sum16(ohi[ib].y)};
+        y[ib] = vec_row_to_col(srow, lane) + grp_sum4(ocol[ib].x + ocol[ib].y);
     }
 }
 template <int VW>
@@ -639,8 +645,8 @@ __device__ __forceinline__ float solve_row_blocked(f32x4 (&acc)[Geo<VW>::NT], fl
                                                    const int lane) {
 #pragma unroll
     for (int t = 0; t < Geo<VW>::NT; ++t) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] += gtiles[(t * 4 + r) * 64 + lane];
+        acc[t] += f32x4{gtiles[(t * 4 + 0) * 64 + lane], gtiles[(t * 4 + 1) * 64 + lane], gtiles[(t * 4 + 2) * 64 + lane],
+                        gtiles[(t * 4 + 3) * 64 + lane]};           // two v_pk_add_f32
         // keep the scheduler from hoisting all NT*4 loads to the top (they would need as many registers)
         if (t % 4 == 3) __builtin_amdgcn_sched_barrier(0);
     }
