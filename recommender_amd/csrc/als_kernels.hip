@@ -222,7 +222,10 @@ template <int VW>
 __device__ __forceinline__ void split_stage(const Stage<VW> &st, const int QB, SplitOps<VW> &o, float (&bacc)[VW]) {
     constexpr int GS = StageGeo<VW>::GS;
     static_assert(VW % 2 == 0, "pairs of factor indices");
-    if constexpr (VW < 8) {      // 3 waves per SIMD: the scalar form needs fewer registers there and is as fast
+#ifndef ALS_SPLIT_PACKED_MIN_VW
+#define ALS_SPLIT_PACKED_MIN_VW 8
+#endif
+    if constexpr (VW < ALS_SPLIT_PACKED_MIN_VW) {      // 3 waves per SIMD: the scalar form needs fewer registers there and is as fast
 #pragma unroll
         for (int p = 0; p < GS / 2; ++p) {
 #pragma unroll
