@@ -121,11 +121,34 @@ def test_topk_ties_exclusions_and_large_rows(ra):
 
 
 def test_scores_edge_shapes(ra):
+    """Both score kernels (f % 4 == 0 and f <= 128: three-way bf16 split on the matrix cores, every
+    k-step count and ragged user / item / factor tails; otherwise float32 products).  The split is
+    exact and the dropped piece products are below 2^-23 of a product, so the error bound is that of
+    a float32 dot product: a few 2^-24 of sum |x_k y_k|."""
     rng = np.random.default_rng(2)
-    for (nu, M, f) in [(1, 1, 5), (65, 257, 20), (3, 1000, 64), (70, 300, 50)]:
+    for (nu, M, f) in [(1, 1, 5), (65, 257, 20), (3, 1000, 64), (70, 300, 50), (129, 33, 36), (200, 4000, 100),
+                       (33, 70, 128), (300, 20000, 96), (5, 16385, 4), (17, 99, 132), (64, 513, 256)]:
         X = rng.normal(size=(nu, f)).astype(np.float32); Y = rng.normal(size=(M, f)).astype(np.float32)
         S = ra.scores(torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda()).cpu().numpy()
-        np.testing.assert_allclose(S, X.astype(np.float64) @ Y.astype(np.float64).T, rtol=1e-5, atol=1e-5)
+        exact = X.astype(np.float64) @ Y.astype(np.float64).T
+        bound = 8 * 2.0 ** -24 * (np.abs(X).astype(np.float64) @ np.abs(Y).astype(np.float64).T) + 1e-30
+        assert np.all(np.abs(S - exact) <= bound), (nu, M, f, float(np.max(np.abs(S - exact) / bound)))
+
+
+def test_scores_user_subset_and_strided_factors(ra):
+    """user_ids picks rows of X; factor matrices may be views with a leading dimension > f; a score
+    does not depend on which other rows or items share the launch."""
+    rng = np.random.default_rng(6)
+    f, ld = 64, 80
+    Xs = torch.from_numpy(rng.normal(size=(500, ld)).astype(np.float32)).cuda()
+    Ys = torch.from_numpy(rng.normal(size=(3000, ld)).astype(np.float32)).cuda()
+    X, Y = Xs[:, :f], Ys[:, :f]
+    users = torch.from_numpy(rng.permutation(500)[:201]).cuda()
+    S = ra.scores(X, Y, users)
+    full = ra.scores(X.contiguous(), Y.contiguous())
+    assert torch.equal(S, full[users])
+    part = ra.scores(X, Y, users[:7], M=1000)
+    assert torch.equal(part, full[users[:7], :1000])
 
 
 def test_update_user_foldin(ra, golden):
