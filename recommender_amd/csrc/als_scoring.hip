@@ -1,11 +1,16 @@
-// Scoring side of libals_hip.so: dense user x item scores on the fp32 matrix cores, exact
-// per-row top-k by radix select, pairwise prediction and row normalisation (cosine similarity).
+// Scoring side of libals_hip.so: dense user x item scores on the matrix cores, exact per-row
+// top-k by radix select, the fused top-k that never stores the score matrix, pairwise prediction
+// and row normalisation (cosine similarity).
 //
-//   scores kernel   one workgroup = 4 waves = a 64-user x 256-item tile; each wave owns 64 x 64
-//                   outputs as 4 x 4 tiles of v_mfma_f32_16x16x4_f32.  Both operands are fetched
-//                   with one 16-byte load per lane: lane (g, i) reads elements 16s+4g .. 16s+4g+3
-//                   of its row, which are 4 consecutive k-steps for lane group g - the k order is
-//                   a permutation shared by both operands, so no staging or shuffling is needed.
+//   scores_split_kernel  f <= 128, 16-byte aligned rows: operands cut exactly into three bf16 pieces,
+//                   6 piece products per block on v_mfma_f32_16x16x32_bf16; item fragments staged
+//                   through LDS (described at the kernel).  FILTER form: the epilogue keeps only
+//                   scores above the user's threshold (fused top-k).
+//   scores_kernel   any f, any alignment: one workgroup = 4 waves = a 64-user x 256-item tile; each
+//                   wave owns 64 x 64 outputs as 4 x 4 tiles of v_mfma_f32_16x16x4_f32.  Both
+//                   operands are fetched with one 16-byte load per lane: lane (g, i) reads elements
+//                   16s+4g .. 16s+4g+3 of its row, which are 4 consecutive k-steps for lane group g -
+//                   the k order is a permutation shared by both operands, so nothing is staged.
 //   top-k kernel    one workgroup per score row: 4 x 8-bit radix-select passes find the k-th
 //                   largest key, a count pass and an ordered ballot compaction collect the
 //                   winners (ties by ascending item id), a bitonic sort in LDS orders them.
