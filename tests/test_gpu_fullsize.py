@@ -1,0 +1,137 @@
+"""Full-size checks on the shapes of the benchmark configurations (MovieLens-25M-shaped matrix,
+f=64; top-100 against 1 M items, f=128), through properties that do not need the CPU oracle to
+walk the whole input: sampled rows (the longest ones included, which are the rows cut into
+chunks) against the float64 oracle, bit-for-bit repeatability, row shards = whole, the sum of the
+per-row changes, and the fused top-k against a selection done by torch on the same scores.
+
+Bounds: factors 1e-4 relative (max-abs error over the sample / max-abs value), the north-star
+bar; 2e-4 for three conjugate-gradient steps (a truncated iteration carries the float32 input
+rounding through every step; the same bound as the small CG tests)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import als_ref, c_oracle  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+LAMB, ALPHA, F = 0.01, 40.0, 64
+
+
+@pytest.fixture(scope="module")
+def c2():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import recommender_amd as ra
+    from recommender_amd import data
+    from recommender_amd.als import init_factors
+    wl = data.WORKLOADS["c2_ml25m_syn"]
+    N, M = wl["n_users"], wl["n_items"]
+    U, Ut = data.synth_matrix(N, M, wl["nnz"], seed=1234, device="cuda")
+    X0, Y0 = init_factors(N, M, F, "tf")
+    return dict(ra=ra, N=N, M=M, U=U, Ut=Ut, X0=X0.astype(np.float32), Y0=Y0.astype(np.float32))
+
+
+def _sample_rows(ptr, rng, n_random, n_longest):
+    lens = np.diff(ptr)
+    longest = np.argsort(-lens, kind="stable")[:n_longest]
+    shortest = np.argsort(lens, kind="stable")[:5]
+    rows = np.unique(np.concatenate([longest, shortest, rng.choice(len(lens), size=n_random, replace=False)]))
+    return rows, lens
+
+
+def _sub_csr(ptr, col, val, rows):
+    lens = ptr[rows + 1] - ptr[rows]
+    sp = np.zeros(len(rows) + 1, dtype=np.int64); np.cumsum(lens, out=sp[1:])
+    idx = np.concatenate([np.arange(ptr[r], ptr[r + 1]) for r in rows])
+    return sp, col[idx], val[idx].astype(np.float64)
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def _check_side(c2, csr_triplet, shape, fixed, own, seed):
+    ra = c2["ra"]
+    ptr_d, col_d, val_d = csr_triplet
+    csr = ra.DeviceCSR(ptr_d, col_d, val_d, shape, "cuda")
+    Yd = torch.from_numpy(fixed).cuda()
+    gc = ra.gram(Yd, LAMB)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    X = torch.from_numpy(own).cuda()
+    d = ra.half_sweep(csr, Yd, gc, X, ALPHA, info=info)
+    assert int(info.item()) == 0
+    # the reported change is the sum of the per-row changes
+    ref_d = (torch.from_numpy(own).cuda().double() - X.double()).abs().sum()
+    assert float(d.item()) == pytest.approx(float(ref_d.item()), rel=1e-6)
+    # sampled rows against the float64 oracle: the longest rows (cut into chunks) are in the sample
+    ptr, col, val = (t.cpu().numpy() for t in csr_triplet)
+    rows, lens = _sample_rows(ptr, np.random.default_rng(seed), 300, 25)
+    assert lens[rows].max() > 2 * 2048                      # rows of several chunks
+    sp, sc, sv = _sub_csr(ptr, col, val, rows)
+    ref = c_oracle.half_sweep(sp, sc, sv, fixed.astype(np.float64), own[rows].astype(np.float64), LAMB, ALPHA,
+                              dtype=np.float64, nthreads=8)
+    got = X[torch.from_numpy(rows).cuda()].cpu().numpy().astype(np.float64)
+    assert _rel(got, ref) < 1e-4, _rel(got, ref)
+    # bit-for-bit repeatable
+    X2 = torch.from_numpy(own).cuda()
+    d2 = ra.half_sweep(csr, Yd, gc, X2, ALPHA)
+    assert torch.equal(X, X2) and float(d.item()) == float(d2.item())
+    # two row shards (balanced by entries, as two devices would hold them) give the same bits
+    from recommender_amd.als import balanced_ranges
+    b = [int(x) for x in balanced_ranges(ptr, 2)]
+    X3 = torch.from_numpy(own).cuda()
+    for r0, r1 in zip(b[:-1], b[1:]):
+        ra.half_sweep(csr.row_range(r0, r1), Yd, gc, X3[r0:r1], ALPHA)
+    assert torch.equal(X, X3)
+    # three conjugate-gradient steps, formed-matrix form, same sample
+    X4 = torch.from_numpy(own).cuda()
+    ra.half_sweep_cg(csr, Yd, gc, X4, ALPHA, 3)
+    rows_cg = rows[:: max(1, len(rows) // 60)]
+    spc, scc, svc = _sub_csr(ptr, col, val, rows_cg)
+    ref_cg = als_ref.half_sweep_cg(spc, scc, svc, fixed.astype(np.float64), own[rows_cg].astype(np.float64), LAMB, ALPHA, 3)
+    got_cg = X4[torch.from_numpy(rows_cg).cuda()].cpu().numpy().astype(np.float64)
+    assert _rel(got_cg, ref_cg) < 2e-4, _rel(got_cg, ref_cg)
+    return X.cpu().numpy()
+
+
+def test_c2_user_and_item_half_sweeps_at_full_size(c2):
+    N, M = c2["N"], c2["M"]
+    X1 = _check_side(c2, c2["U"], (N, M), c2["Y0"], c2["X0"], seed=1)
+    _check_side(c2, c2["Ut"], (M, N), X1, c2["Y0"], seed=2)
+
+
+def test_c5_fused_topk_at_one_million_items():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import recommender_amd as ra
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    f, M, nu, k = 128, 1_000_000, 300, 100
+    X = torch.randn((4000, f), generator=g, device="cuda") / f ** 0.5
+    Y = torch.randn((M, f), generator=g, device="cuda") / f ** 0.5
+    users = torch.randperm(4000, generator=g, device="cuda")[:nu]
+    rng = np.random.default_rng(0)
+    ex_rows = [np.sort(rng.choice(M, size=int(c), replace=False)).astype(np.int32) for c in rng.integers(0, 400, size=nu)]
+    ptr = np.zeros(nu + 1, dtype=np.int64); np.cumsum([len(r) for r in ex_rows], out=ptr[1:])
+    # exclusions are given per user id over ALL users: scatter the block's rows into a full CSR
+    full_rows = [np.zeros(0, np.int32)] * 4000
+    for u, r in zip(users.cpu().numpy(), ex_rows):
+        full_rows[u] = r
+    fptr = np.zeros(4001, dtype=np.int64); np.cumsum([len(r) for r in full_rows], out=fptr[1:])
+    ex = (fptr, np.concatenate(full_rows))
+    idx, val = ra.ops.recommend_topk(X, Y, users, k, exclude_csr=ex)
+    # the selection done by torch on the library's own scores (same arithmetic, so the same bits)
+    S = ra.scores(X, Y, users)
+    for j, r in enumerate(ex_rows):
+        S[j, torch.from_numpy(r.astype(np.int64)).cuda()] = -float("inf")
+    tv, ti = torch.topk(S, k, dim=1, sorted=True)
+    assert torch.equal(val, tv)
+    assert (idx.long() == ti).float().mean().item() > 0.9999        # equal scores may swap in torch's order, not in ours
+    assert bool((val[:, :-1] >= val[:, 1:]).all())
+    for j in range(0, nu, 29):
+        got = idx[j].cpu().numpy()
+        assert len(np.unique(got)) == k and not np.intersect1d(got, ex_rows[j]).size
+    # float32-exact dot products agree to rounding
+    exact = (X[users[:16]].double() @ Y.double().T).gather(1, idx[:16].long())
+    assert float((val[:16].double() - exact).abs().max()) < 2e-6
