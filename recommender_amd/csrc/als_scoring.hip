@@ -352,31 +352,27 @@ __global__ __launch_bounds__(256, 2) void scores_split_kernel(const float *__res
         // C layout: lane (g, j), register r holds (user 4g + r, item j) of each 16 x 16 tile
         if constexpr (FILTER) {
             flush();                 // last stage's hit: its slot number has arrived by now
-            bool any_hit = false;    // most stages of most waves hold no score above a threshold: one test for all 16
+            // most (user row, stage) pairs hold no score above the row's threshold: one wave-wide test
+            // per register (4 user rows x 32 items), the per-score code only behind it
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) any_hit = any_hit || fmaxf(acc[0][a][r], acc[1][a][r]) > tau[a][r];
-            if (__any(any_hit)) {
+                for (int r = 0; r < 4; ++r) {
+                    if (!__any(fmaxf(acc[0][a][r], acc[1][a][r]) > tau[a][r])) continue;
+                    const int64_t u = u0 + 16 * a + 4 * g + r;
+                    if (u >= nu) continue;
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int64_t u = u0 + 16 * a + 4 * g + r;
-                        if (u >= nu) continue;
-#pragma unroll
-                        for (int it = 0; it < 2; ++it) {
-                            const int64_t i = item_begin + t * SB_ITEMS + it * 16 + j;
-                            const float sc = acc[it][a][r];
-                            if (i < M && sc > tau[a][r] && !excluded_item(cand, u, (int)i)) {
-                                flush();             // only a lane's second hit within one stage waits here
-                                pend = true;
-                                pend_pos = atomicAdd(&cand.count[u], 1);      // integer: which slot, not what value
-                                pend_sc = sc; pend_item = (int32_t)i; pend_row = u * cand.cap;
-                            }
+                    for (int it = 0; it < 2; ++it) {
+                        const int64_t i = item_begin + t * SB_ITEMS + it * 16 + j;
+                        const float sc = acc[it][a][r];
+                        if (i < M && sc > tau[a][r] && !excluded_item(cand, u, (int)i)) {
+                            flush();             // only a lane's second hit within one stage waits here
+                            pend = true;
+                            pend_pos = atomicAdd(&cand.count[u], 1);      // integer: which slot, not what value
+                            pend_sc = sc; pend_item = (int32_t)i; pend_row = u * cand.cap;
                         }
                     }
-            }
+                }
         } else {
 #pragma unroll
             for (int a = 0; a < 2; ++a)
