@@ -225,3 +225,37 @@ def test_accumulate_modes_agree_and_both_hold_parity(ra, f):
     finally:
         ra.ops.set_accumulate_mode("bf16x3")
     assert _rel(out["bf16x3"], out["fp32"]) < 2e-5
+
+
+def test_integration_stub_from_the_docs_runs(ra):
+    """The ctypes binding printed in INTEGRATION.md (operator level: plan, Gram cache, half-sweep),
+    executed as printed, reproduces the oracle's half-sweep."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = next(b for b in blocks if "def run_epoch" in b)
+    stub = stub.replace('"recommender_amd/libals_hip.so"', repr(os.path.join(root, "recommender_amd", "libals_hip.so")))
+    ns = {}
+    exec(compile(stub, "INTEGRATION.md", "exec"), ns)
+    lib = ns["lib"]
+    rng = np.random.default_rng(12)
+    N, M, f, lamb, alpha = 400, 3000, 20, 0.01, 40.0
+    ptr, ind, dat = _random_csr(rng, N, M, 30, 2500)         # one row longer than a chunk
+    Y0 = rng.normal(0, 1 / np.sqrt(f), size=(M, f)).astype(np.float32)
+    X0 = rng.normal(0, 1 / np.sqrt(f), size=(N, f)).astype(np.float32)
+    plan = ns["make_plan"](np.ascontiguousarray(ptr, dtype=np.int64))
+    Y, X = _dev(Y0), _dev(X0)
+    gram = torch.empty((f, f), device="cuda")
+    tiles = torch.empty(lib.als_gram_tiles_bytes(f), dtype=torch.uint8, device="cuda")
+    ws = torch.empty(max(lib.als_gram_workspace_bytes(M, f), 256), dtype=torch.uint8, device="cuda")
+    ns["update_cache"](Y, lamb, gram, tiles, ws)
+    ws2 = torch.empty(max(lib.als_half_sweep_workspace_bytes(N, plan[3], f), 256), dtype=torch.uint8, device="cuda")
+    absdiff = torch.zeros(1, dtype=torch.float64, device="cuda")
+    mean_change = ns["run_epoch"](_dev(ptr, torch.int64), _dev(ind, torch.int32), _dev(dat), plan, Y, tiles, X, alpha,
+                                  absdiff, ws2)
+    torch.cuda.synchronize()
+    ref = c_oracle.half_sweep(ptr, ind, dat, Y0, X0, lamb, alpha, dtype=np.float64, nthreads=4)
+    assert _rel(X.cpu().numpy().astype(np.float64), ref) < 1e-4
+    assert float(mean_change.item()) == pytest.approx(np.abs(X0.astype(np.float64) - ref).mean(), rel=1e-4)
