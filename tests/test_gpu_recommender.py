@@ -308,3 +308,26 @@ def test_device_transpose_equals_scipy(ra):
     assert np.array_equal(t.rowptr.cpu().numpy(), Ut.indptr)
     assert np.array_equal(t.col.cpu().numpy(), Ut.indices)
     assert np.array_equal(t.val.cpu().numpy(), Ut.data.astype(np.float32))
+
+
+@pytest.mark.parametrize("nu,M,f,k", [(1, 16385, 4, 1), (3, 16384, 8, 16), (5, 16416, 64, 100), (2, 65537, 128, 1024),
+                                      (129, 20000, 36, 1024), (7, 300000, 100, 200), (33, 70000, 132, 50),
+                                      (4, 1024, 16, 1024), (130, 262145, 32, 7)])
+def test_fused_topk_edge_shapes(ra, nu, M, f, k):
+    """Range boundaries of the fused path (one item past the first range, exactly the first range, a
+    first range shorter than 16 k, k = 1024, a single user, the float32 kernel at f = 132), without
+    exclusions and with all but 2k+5 items of every user excluded: same bits as the two-call path."""
+    rng = np.random.default_rng(nu + M + f + k)
+    X = torch.from_numpy(rng.integers(-3, 4, size=(nu + 3, f)).astype(np.float32) / 4).cuda()
+    Y = torch.from_numpy(rng.integers(-3, 4, size=(M, f)).astype(np.float32) / 4).cuda()
+    users = torch.arange(nu, device="cuda") + 2
+    i0, v0 = _two_call(ra, X, Y, users, k, None)
+    i1, v1 = ra.ops.recommend_topk(X, Y, users, k)
+    assert torch.equal(i0, i1) and torch.equal(v0, v1)
+    keep = [np.sort(rng.choice(M, size=min(M, 2 * k + 5), replace=False)) for _ in range(nu + 3)]
+    rows = [np.setdiff1d(np.arange(M), kp).astype(np.int32) for kp in keep]
+    ptr = np.zeros(nu + 4, dtype=np.int64); np.cumsum([len(r) for r in rows], out=ptr[1:])
+    ex = (ptr, np.concatenate(rows))
+    j0, w0 = _two_call(ra, X, Y, users, k, ex)
+    j1, w1 = ra.ops.recommend_topk(X, Y, users, k, exclude_csr=ex)
+    assert torch.equal(j0, j1) and torch.equal(w0, w1)
