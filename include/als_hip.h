@@ -166,7 +166,8 @@ int32_t als_half_sweep_csr_f32(const int64_t *rowptr, const int32_t *col, const 
  * solved (A_u is never formed: A_u v = gram v + sum_j alpha r_uj (y_j . v) y_j + lamb v).
  * No counterpart in the reference, which inverts A_u (reclibwh/core/ALS.py:82,172); it is the
  * solver for factor counts whose f x f system no longer fits one wavefront's registers.
- * With cg_steps >= f it reproduces the exact solve to rounding.  A row without entries gets 0.
+ * With cg_steps >= f it reproduces the exact solve to rounding.  A row without entries, or with
+ * nothing but stored zeros (which are dropped, ALS.py:79), gets its exact solution 0.
  *
  * Implementations of the same iteration, chosen by `form`:
  *   ALS_CG_FORM_MATRIX     ONE gather pass forms the row's matrix in accumulator registers exactly as

@@ -154,8 +154,10 @@ __device__ __forceinline__ void cg_compute(const CgStage<VW> &st, const float (&
 }
 
 // Entries [s, e) of the CSR (wave uniform, e > s), w = alpha r, c = 1 + alpha r (0 for a stored 0).
+// Returns whether any entry of the range has a non-zero rating (stored zeros are dropped, ALS.py:79: a
+// row that holds nothing else has the exact solution 0).
 template <int VW, bool VEC, bool INIT>
-__device__ __forceinline__ void cg_accumulate(float (&acc)[VW], const float (&dv)[VW], const int32_t *__restrict__ col,
+__device__ __forceinline__ bool cg_accumulate(float (&acc)[VW], const float (&dv)[VW], const int32_t *__restrict__ col,
                                               const float *__restrict__ val, const int64_t s, const int64_t e,
                                               const float *__restrict__ Y, const int64_t ld, const int f,
                                               const float alpha, const int lane) {
@@ -163,6 +165,7 @@ __device__ __forceinline__ void cg_accumulate(float (&acc)[VW], const float (&dv
     CgStage<VW> A, B;
     int cur_col, nxt_col = 0;
     float cur_w, cur_cw, nxt_w = 0.f, nxt_cw = 0.f;
+    bool kept = false;
     auto load_chunk = [&](const int64_t base, int &c, float &w, float &cw) {
         const int64_t idx = base + lane;
         const bool ok = idx < e;
@@ -173,6 +176,7 @@ __device__ __forceinline__ void cg_accumulate(float (&acc)[VW], const float (&dv
         c = cc;                                   // a lane past the end re-reads entry s with weight 0
         w = ok ? ww : 0.f;
         cw = (ok && rr != 0.f) ? 1.f + ww : 0.f;
+        kept = kept || (ok && rr != 0.f);
     };
     load_chunk(s, cur_col, cur_w, cur_cw);
     cg_issue<VW, VEC, INIT>(A, 0, cur_col, cur_w, cur_cw, Y, ld, f, lane);
@@ -197,6 +201,7 @@ __device__ __forceinline__ void cg_accumulate(float (&acc)[VW], const float (&dv
             if (ng > g) cg_compute<VW, INIT>(cur, dv, acc);
         }
     }
+    return __any(kept);
 }
 
 // the 4 lane groups hold partial sums of the same elements: (g0 + g1) + (g2 + g3) in every group
@@ -333,15 +338,16 @@ __global__ __launch_bounds__(64) void cg_items_kernel(const CgParams p) {
     cg_load_direction<VW, VEC, MODE>(p, row, lane & 15, dv);
 #pragma unroll
     for (int t = 0; t < VW; ++t) acc[t] = 0.f;
+    bool kept = false;
     if (e > s) {
-        cg_accumulate<VW, VEC, MODE == CG_INIT>(acc, dv, p.col, p.val, s, e, p.Y, p.ldy, p.f, p.alpha, lane);
+        kept = cg_accumulate<VW, VEC, MODE == CG_INIT>(acc, dv, p.col, p.val, s, e, p.Y, p.ldy, p.f, p.alpha, lane);
         reduce_groups<VW>(acc);
     }
     if (it.chunk >= 0) {
         if (lane < 16) store_row<VW, true>(p.slots + (int64_t)it.slot * (16 * VW), 16 * VW, lane, acc);
         return;
     }
-    cg_finish<VW, VEC, MODE>(p, row, e > s, acc, dv, lane);
+    cg_finish<VW, VEC, MODE>(p, row, kept, acc, dv, lane);      // (a row cut into chunks counts as holding ratings)
 }
 
 // A long row: add its chunk sums in chunk order, then finish as above.

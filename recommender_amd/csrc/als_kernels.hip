@@ -662,9 +662,15 @@ __device__ __forceinline__ float solve_row_blocked(f32x4 (&acc)[Geo<VW>::NT], fl
     }
     bool ok;
     if (cg_steps > 0) {
+        // b = 0: the row holds nothing but stored zeros, which are dropped (ALS.py:79) - its solution is 0, and
+        // it gets it rather than cg_steps steps towards it (the exact solve returns 0 by itself)
+        bool has_b = false;
 #pragma unroll
-        for (int t = 0; t < VW; ++t) x[t] = xold[t];
-        ok = tiles_cg<VW>(acc, bacc, x, cg_steps, lane);
+        for (int t = 0; t < VW; ++t) has_b = has_b || bacc[t] != 0.f;
+        has_b = __any(has_b);
+#pragma unroll
+        for (int t = 0; t < VW; ++t) x[t] = has_b ? xold[t] : 0.f;
+        ok = has_b ? tiles_cg<VW>(acc, bacc, x, cg_steps, lane) : true;
     } else {
         ok = blocked_solve<VW>(acc, bacc, x, lane);
     }

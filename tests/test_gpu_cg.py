@@ -190,3 +190,25 @@ def test_engine_cg_f256_tracks_oracle(ra):
     assert int(eng.info.item()) == 0
     with pytest.raises(ValueError):
         ALSEngine(eng.csr_users, eng.csr_items, X, Y, lamb, alpha, solver="cholesky")
+
+
+@pytest.mark.parametrize("f,form", [(20, "auto"), (64, "matrix"), (64, "lock_step"), (127, "auto"), (200, "lock_step"),
+                                    (200, "matrix")])
+def test_cg_rows_of_stored_zeros_get_zero(ra, f, form):
+    """Stored zeros are dropped (ALS.py:79): a row whose only entries are zeros has the exact solution
+    0 and gets it in every CG form, as in the oracle - not cg_steps steps towards it; rows that mix zeros
+    and ratings ignore the zeros."""
+    rng = np.random.default_rng(f)
+    N, M = 60, 500
+    ptr, ind, dat = _random_csr(rng, N, M, 30, 300)
+    lens = np.diff(ptr)
+    rows0 = [r for r in np.flatnonzero(lens > 0)[:6]]                       # these rows: nothing but stored zeros
+    for r in rows0:
+        dat[ptr[r]:ptr[r + 1]] = 0.0
+    dat[rng.integers(0, len(dat), size=len(dat) // 10)] = 0.0                # and zeros sprinkled over the others
+    Y0 = rng.normal(0, 1 / np.sqrt(f), size=(M, f)).astype(np.float32)
+    X0 = rng.normal(0, 1 / np.sqrt(f), size=(N, f)).astype(np.float32)
+    ref = als_ref.half_sweep_cg(ptr, ind, dat.astype(np.float64), Y0.astype(np.float64), X0.astype(np.float64), 0.1, 10.0, 3)
+    X, _ = _sweep_cg(ra, ptr, ind, dat, (N, M), Y0, X0, 0.1, 10.0, 3, form=form)
+    assert np.all(X[rows0] == 0.0) and np.all(ref[rows0] == 0.0)
+    assert _rel(X, ref) < 2e-4
