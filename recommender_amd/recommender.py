@@ -220,7 +220,9 @@ class RecommenderALS:
         vals = np.asarray(vals, dtype=np.float64)
         if len(rows) == 0:
             return
-        if rows.max() >= self.X.shape[0] or cols.max() >= self.n_items:
+        if not (len(rows) == len(cols) == len(vals)):
+            raise ValueError("rows, cols and vals must have the same length")
+        if rows.min() < 0 or cols.min() < 0 or rows.max() >= self.X.shape[0] or cols.max() >= self.n_items:
             raise ValueError("row or column id outside the model")
         uniq, inv = np.unique(rows, return_inverse=True)
         U = sps.csr_matrix((vals, (inv, cols)), shape=(len(uniq), self.n_items))   # duplicates sum, as csr_matrix does
