@@ -783,7 +783,15 @@ __global__ __launch_bounds__(256) void sum_slots_kernel(float *__restrict__ part
     if (e >= elems) return;
     float *P = partials + (int64_t)lr.first_slot * elems + e;
     float acc = P[0];
-    for (int c = 1; c < lr.n_chunks; ++c) acc += P[(int64_t)c * elems];
+    int c = 1;
+    for (; c + 7 < lr.n_chunks; c += 8) {      // 8 loads in flight, added in chunk order
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = P[(int64_t)(c + q) * elems];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += v[q];
+    }
+    for (; c < lr.n_chunks; ++c) acc += P[(int64_t)c * elems];
     P[0] = acc;
 }
 
