@@ -854,7 +854,15 @@ __global__ __launch_bounds__(64 * SUM_SUBS) void sum_groups_kernel(const float *
     float acc = 0.f;
     if (e < elems && first < last) {
         acc = in[first * elems + e];
-        for (int64_t i = first + 1; i < last; ++i) acc += in[i * elems + e];
+        int64_t i = first + 1;
+        for (; i + 7 < last; i += 8) {          // 8 loads in flight, added in order
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = in[(i + q) * elems + e];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += v[q];
+        }
+        for (; i < last; ++i) acc += in[i * elems + e];
     }
     part[threadIdx.y][threadIdx.x] = acc;
     __syncthreads();
