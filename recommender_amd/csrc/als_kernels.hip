@@ -912,7 +912,15 @@ __global__ __launch_bounds__(256) void sum_to_double_kernel(const T *__restrict_
     const int64_t first = (int64_t)blockIdx.x * per_block;
     const int64_t last = min(n, first + per_block);
     double acc = 0.0;
-    for (int64_t i = first + threadIdx.x; i < last; i += 256) acc += (double)in[i];
+    int64_t i = first + threadIdx.x;
+    for (; i + 7 * 256 < last; i += 8 * 256) {      // 8 loads in flight, added in order
+        T v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = in[i + q * 256];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += (double)v[q];
+    }
+    for (; i < last; i += 256) acc += (double)in[i];
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (int o = 128; o >= 1; o >>= 1) {
