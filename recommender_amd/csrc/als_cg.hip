@@ -486,7 +486,15 @@ __global__ void wide_sum_groups_kernel(const float *__restrict__ in, const int64
     const int64_t g = blockIdx.y;
     const int64_t first = g * group, last = min(n_in, first + group);
     float acc = in[first * elems + e];
-    for (int64_t i = first + 1; i < last; ++i) acc += in[i * elems + e];
+    int64_t i = first + 1;
+    for (; i + 7 < last; i += 8) {          // 8 loads in flight, added in order
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = in[(i + q) * elems + e];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += v[q];
+    }
+    for (; i < last; ++i) acc += in[i * elems + e];
     out[g * elems + e] = acc;
 }
 
