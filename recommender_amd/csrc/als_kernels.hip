@@ -529,6 +529,11 @@ __device__ __forceinline__ f32x4 diag_inverse_factor(f32x4 D, const int lane, bo
 template <int VW>
 __device__ __forceinline__ bool blocked_solve(f32x4 (&T)[Geo<VW>::NT], float (&b)[VW], float (&x)[VW], const int lane) {
     float zcol[VW];
+    // forward substitution: b_ib -= sum_kb U_kb,ib^T z_kb.  The per-lane products of all block steps are
+    // added up first and reduced over the lane groups once, when block ib's turn comes.
+    float pend[VW];
+#pragma unroll
+    for (int t = 0; t < VW; ++t) pend[t] = 0.f;
     bool ok = true;
 #pragma unroll
     for (int kb = 0; kb < VW; ++kb) {
@@ -541,6 +546,7 @@ __device__ __forceinline__ bool blocked_solve(f32x4 (&T)[Geo<VW>::NT], float (&b
             tile_xtz<false>(X, T[tile_index(kb, jb, VW)], u);
             T[tile_index(kb, jb, VW)] = u;
         }
+        if (kb > 0) b[kb] -= grp_sum4(pend[kb]);
         zcol[kb] = tile_xt_v(X, vec_col_to_row(b[kb], lane));          // z_kb = U_kk^{-T} b_kb
         const f32x4 zrow = vec_col_to_row(zcol[kb], lane);
 #pragma unroll
@@ -549,15 +555,22 @@ __device__ __forceinline__ bool blocked_solve(f32x4 (&T)[Geo<VW>::NT], float (&b
             const f32x4 nUi = -Ui;
 #pragma unroll
             for (int jb = ib; jb < VW; ++jb) tile_xtz<false>(nUi, T[tile_index(kb, jb, VW)], T[tile_index(ib, jb, VW)]);
-            b[ib] -= tile_xt_v(Ui, zrow);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pend[ib] = fmaf(Ui[r], zrow[r], pend[ib]);
         }
         __builtin_amdgcn_sched_barrier(0);   // block steps stay in order: bounds the live ranges
     }
+    // back substitution: the per-lane products of a block row are added up first, one lane reduction per block
 #pragma unroll
     for (int kb = VW - 1; kb >= 0; --kb) {
-        f32x4 acc = vec_col_to_row(zcol[kb], lane);
+        f32x4 part = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int jb = kb + 1; jb < VW; ++jb) acc -= tile_x_v(T[tile_index(kb, jb, VW)], x[jb]);
+        for (int jb = kb + 1; jb < VW; ++jb) part += T[tile_index(kb, jb, VW)] * x[jb];
+        f32x4 acc = vec_col_to_row(zcol[kb], lane);
+        if (kb + 1 < VW) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] -= row_sum16(part[r]);
+        }
         x[kb] = vec_row_to_col(tile_x_v(T[tile_index(kb, kb, VW)], vec_row_to_col(acc, lane)), lane);
     }
     return ok;
