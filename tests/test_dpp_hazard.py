@@ -1,0 +1,35 @@
+"""The hand-written `v_fmac_f32_dpp` statements of the solve rely on the two wait states between a vector write of a
+register and a DPP read of it, which the compiler does not provide inside an asm statement: the generated code of
+the shipped kernels must keep that distance (tools/check_dpp_hazard.py)."""
+import importlib.util
+import os
+import shutil
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_spec = importlib.util.spec_from_file_location("check_dpp_hazard", os.path.join(ROOT, "tools", "check_dpp_hazard.py"))
+chk = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(chk)
+
+DPP = "\tv_fmac_f32_dpp v5, v5, v9 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+
+
+def test_checker_flags_a_write_right_before_the_dpp_read():
+    assert chk.check("_Zk:\n\tv_mov_b32_e32 v5, v7\n" + DPP)
+    assert chk.check("_Zk:\n\tv_accvgpr_read_b32 v5, a3\n\tv_add_f32_e32 v1, v2, v3\n" + DPP)
+    assert chk.check("_Zk:\n\tv_pk_add_f32 v[4:5], v[0:1], v[2:3]\n" + DPP)
+
+
+def test_checker_accepts_two_wait_states():
+    assert not chk.check("_Zk:\n\tv_mov_b32_e32 v5, v7\n\ts_nop 1\n" + DPP)
+    assert not chk.check("_Zk:\n\tv_mov_b32_e32 v5, v7\n\tv_add_f32_e32 v1, v2, v3\n\tv_add_f32_e32 v2, v2, v3\n" + DPP)
+    assert not chk.check("_Zk:\n\tv_mov_b32_e32 v6, v7\n" + DPP)                 # another register
+    assert not chk.check("_Zk:\n\tv_mov_b32_e32 v9, v7\n" + DPP)                 # the plain (non-DPP) source
+
+
+@pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="needs hipcc")
+def test_shipped_solve_kernels_keep_the_distance():
+    text = chk.assembly_of(os.path.join(chk.CSRC, "als_kernels.hip"))
+    assert text.count("v_fmac_f32_dpp") > 1000            # the statements are there
+    assert chk.check(text) == []

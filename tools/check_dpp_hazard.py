@@ -1,0 +1,98 @@
+"""Build-time check of the hand-written DPP statements in the solve (als_kernels.hip, fmac_bcast).
+
+On gfx9 a VGPR written by a vector ALU instruction may be read through DPP two wait states later at the
+earliest, and the hardware does not interlock this.  The compiler inserts the wait states for its own
+instructions but does not look inside an asm statement, so a register copy that the register allocator
+places directly in front of one of the asm `v_fmac_f32_dpp` statements would make it read a stale value.
+This script compiles the kernels to assembly with the Makefile's flags and verifies, for every
+`v_fmac_f32_dpp vD, vD, vS`, that no vector ALU instruction writes vD in the two wait states before it.
+
+usage: python tools/check_dpp_hazard.py [file.s ...]     (no arguments: compiles recommender_amd/csrc/*.hip)
+exit status 0: clean, 1: hazards found (printed with their kernel and line)."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "recommender_amd", "csrc")
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize"]          # the Makefile's CXXFLAGS that affect code generation
+SOURCES = ["als_kernels.hip", "als_cg.hip", "als_scoring.hip"]
+
+_reg = re.compile(r"^v(\d+)$")
+_range = re.compile(r"^v\[(\d+):(\d+)\]$")
+
+
+def _written(operand):
+    """VGPR numbers named by a destination operand."""
+    m = _reg.match(operand)
+    if m:
+        return {int(m.group(1))}
+    m = _range.match(operand)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+def check(text):
+    """Returns a list of (kernel, line number, instruction, offending earlier instruction)."""
+    bad = []
+    kernel = "?"
+    window = []          # (wait states this instruction provides, registers it writes by VALU, text), newest last
+    for no, raw in enumerate(text.split("\n"), 1):
+        line = raw.split(";")[0].strip()
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            kernel, window = m.group(1), []
+            continue
+        if not line or line.startswith(".") or line.endswith(":"):
+            continue
+        parts = line.split(None, 1)
+        op = parts[0]
+        args = [a.strip() for a in parts[1].split(",")] if len(parts) > 1 else []
+        if op == "v_fmac_f32_dpp" and args:
+            src = _written(args[0])
+            states = 0
+            for ws, wr, txt in reversed(window):
+                if states >= 2:
+                    break
+                if wr & src:
+                    bad.append((kernel, no, line, txt))
+                    break
+                states += ws
+        if op == "s_nop":
+            window.append((int(args[0], 0) + 1, set(), line))
+        elif op.startswith("v_") and args and not op.startswith("v_cmp") and not op.startswith("v_readlane") \
+                and not op.startswith("v_readfirstlane"):
+            window.append((1, _written(args[0]), line))
+        else:
+            window.append((1, set(), line))
+        if len(window) > 8:
+            window.pop(0)
+    return bad
+
+
+def assembly_of(src):
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "k.s")
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        subprocess.run([hipcc, "--offload-arch=gfx950", *FLAGS, "-I" + os.path.join(ROOT, "include"), "-S",
+                        "--cuda-device-only", "-o", out, src], check=True, cwd=CSRC, stderr=subprocess.DEVNULL)
+        return open(out).read()
+
+
+def main(argv):
+    texts = [(p, open(p).read()) for p in argv] if argv else [(s, assembly_of(os.path.join(CSRC, s))) for s in SOURCES]
+    total = n_dpp = 0
+    for name, text in texts:
+        n_dpp += len(re.findall(r"^\s*v_fmac_f32_dpp", text, flags=re.M))
+        for kernel, no, ins, prev in check(text):
+            total += 1
+            print(f"{name}:{no}: {kernel[:60]}: `{ins}` reads a register written by `{prev}` less than 2 wait states before")
+    print(f"{n_dpp} v_fmac_f32_dpp statements checked, {total} hazards")
+    return 1 if total else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))
