@@ -450,7 +450,9 @@ __device__ __forceinline__ f32x4 tile_x_v(const f32x4 &X, const float vcol) {
 // written by a vector instruction may be read through DPP two wait states later at the earliest)
 // is handled here: the statements are volatile, hence stay in program order, and every register
 // is touched at most once per elimination step (4 to 8 statements apart); GUARD adds the wait states for the
-// one step whose source was last written by compiler-scheduled code.
+// first statement on each register after step 0, whose source was last written by compiler-scheduled code
+// that the scheduler may place directly in front of it (step 1 for most, steps 2 and 3 for N's registers 2
+// and 3, which steps 1 and 2 leave alone).  tools/check_dpp_hazard.py verifies the generated code.
 #define ALS_FMAC_BCAST_CASE(n)                                                                            \
     if constexpr (K == n) {                                                                               \
         if constexpr (GUARD)                                                                              \
@@ -496,8 +498,8 @@ __device__ __forceinline__ void diag_step(f32x4 &D, f32x4 &N, const int c) {
         if constexpr (K < 15) fmac_bcast<K, K == 1>(d3, nv);
         fmac_bcast<K, K == 1>(n0, nv);
         fmac_bcast<K, K == 1>(n1, nv);
-        if constexpr (K >= 2) fmac_bcast<K, K == 1>(n2, nv);
-        if constexpr (K >= 3) fmac_bcast<K, K == 1>(n3, nv);
+        if constexpr (K >= 2) fmac_bcast<K, K == 2>(n2, nv);   // n2, n3: step 0's result is still their last write
+        if constexpr (K >= 3) fmac_bcast<K, K == 3>(n3, nv);
         D = f32x4{d0, d1, d2, d3};
         N = f32x4{n0, n1, n2, n3};
     }
