@@ -4,8 +4,10 @@ On gfx9 a VGPR written by a vector ALU instruction may be read through DPP two w
 earliest, and the hardware does not interlock this.  The compiler inserts the wait states for its own
 instructions but does not look inside an asm statement, so a register copy that the register allocator
 places directly in front of one of the asm `v_fmac_f32_dpp` statements would make it read a stale value.
-This script compiles the kernels to assembly with the Makefile's flags and verifies, for every
-`v_fmac_f32_dpp vD, vD, vS`, that no vector ALU instruction writes vD in the two wait states before it.
+This script compiles the kernels to assembly with the Makefile's flags and verifies, for every DPP
+instruction (the hand-written `v_fmac_f32_dpp vD, vD, vS` and the compiler's own, which may read a
+register that an asm statement wrote), that no vector ALU instruction writes the register read through
+DPP in the two wait states before it.
 
 usage: python tools/check_dpp_hazard.py [file.s ...]     (no arguments: compiles recommender_amd/csrc/*.hip)
 exit status 0: clean, 1: hazards found (printed with their kernel and line)."""
@@ -51,8 +53,8 @@ def check(text):
         parts = line.split(None, 1)
         op = parts[0]
         args = [a.strip() for a in parts[1].split(",")] if len(parts) > 1 else []
-        if op == "v_fmac_f32_dpp" and args:
-            src = _written(args[0])
+        if op.endswith("_dpp") and len(args) > 1:
+            src = _written(args[1])      # the operand read through DPP (for v_fmac_f32_dpp d, d, s the destination itself)
             states = 0
             for ws, wr, txt in reversed(window):
                 if states >= 2:
@@ -86,11 +88,11 @@ def main(argv):
     texts = [(p, open(p).read()) for p in argv] if argv else [(s, assembly_of(os.path.join(CSRC, s))) for s in SOURCES]
     total = n_dpp = 0
     for name, text in texts:
-        n_dpp += len(re.findall(r"^\s*v_fmac_f32_dpp", text, flags=re.M))
+        n_dpp += len(re.findall(r"^\s*v_\w+_dpp\s", text, flags=re.M))
         for kernel, no, ins, prev in check(text):
             total += 1
             print(f"{name}:{no}: {kernel[:60]}: `{ins}` reads a register written by `{prev}` less than 2 wait states before")
-    print(f"{n_dpp} v_fmac_f32_dpp statements checked, {total} hazards")
+    print(f"{n_dpp} DPP instructions checked, {total} hazards")
     return 1 if total else 0
 
 
