@@ -33,3 +33,10 @@ def test_shipped_solve_kernels_keep_the_distance():
     text = chk.assembly_of(os.path.join(chk.CSRC, "als_kernels.hip"))
     assert text.count("v_fmac_f32_dpp") > 1000            # the statements are there
     assert chk.check(text) == []
+
+
+def test_checker_flags_a_matrix_core_result_read_too_early():
+    mfma = "\tv_mfma_f32_16x16x4_f32 v[4:7], v1, v2, v[4:7]\n"
+    assert chk.check("_Zk:\n" + mfma + "\tv_add_f32_e32 v1, v2, v3\n" * 5 + DPP)
+    assert not chk.check("_Zk:\n" + mfma + "\tv_add_f32_e32 v1, v2, v3\n" * 18 + DPP)
+    assert not chk.check("_Zk:\n" + mfma + "\ts_nop 7\n\ts_nop 7\n\ts_nop 1\n" + DPP)

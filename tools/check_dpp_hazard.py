@@ -7,7 +7,7 @@ places directly in front of one of the asm `v_fmac_f32_dpp` statements would mak
 This script compiles the kernels to assembly with the Makefile's flags and verifies, for every DPP
 instruction (the hand-written `v_fmac_f32_dpp vD, vD, vS` and the compiler's own, which may read a
 register that an asm statement wrote), that no vector ALU instruction writes the register read through
-DPP in the two wait states before it.
+DPP in the two wait states before it, and no matrix-core instruction in the 18 before it.
 
 usage: python tools/check_dpp_hazard.py [file.s ...]     (no arguments: compiles recommender_amd/csrc/*.hip)
 exit status 0: clean, 1: hazards found (printed with their kernel and line)."""
@@ -22,6 +22,7 @@ CSRC = os.path.join(ROOT, "recommender_amd", "csrc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize"]          # the Makefile's CXXFLAGS that affect code generation
 SOURCES = ["als_kernels.hip", "als_cg.hip", "als_scoring.hip"]
 
+MFMA_STATES = 18
 _reg = re.compile(r"^v(\d+)$")
 _range = re.compile(r"^v\[(\d+):(\d+)\]$")
 
@@ -41,7 +42,7 @@ def check(text):
     """Returns a list of (kernel, line number, instruction, offending earlier instruction)."""
     bad = []
     kernel = "?"
-    window = []          # (wait states this instruction provides, registers it writes by VALU, text), newest last
+    window = []          # (wait states this instruction provides, registers it writes, text, wait states a DPP read needs), newest last
     for no, raw in enumerate(text.split("\n"), 1):
         line = raw.split(";")[0].strip()
         m = re.match(r"^(_Z\w+):", line)
@@ -56,21 +57,26 @@ def check(text):
         if op.endswith("_dpp") and len(args) > 1:
             src = _written(args[1])      # the operand read through DPP (for v_fmac_f32_dpp d, d, s the destination itself)
             states = 0
-            for ws, wr, txt in reversed(window):
-                if states >= 2:
+            for ws, wr, txt, need in reversed(window):
+                if states >= MFMA_STATES:
                     break
                 if wr & src:
-                    bad.append((kernel, no, line, txt))
+                    if states < need:
+                        bad.append((kernel, no, line, txt))
                     break
                 states += ws
         if op == "s_nop":
-            window.append((int(args[0], 0) + 1, set(), line))
+            window.append((int(args[0], 0) + 1, set(), line, 0))
+        elif op.startswith("v_mfma") and args:
+            # a matrix-core result is not interlocked against a vector read either (up to 18 wait states for the
+            # longest instruction used here); the statements of the solve never follow one that closely
+            window.append((1, _written(args[0]), line, MFMA_STATES))
         elif op.startswith("v_") and args and not op.startswith("v_cmp") and not op.startswith("v_readlane") \
                 and not op.startswith("v_readfirstlane"):
-            window.append((1, _written(args[0]), line))
+            window.append((1, _written(args[0]), line, 2))
         else:
-            window.append((1, set(), line))
-        if len(window) > 8:
+            window.append((1, set(), line, 0))
+        if len(window) > MFMA_STATES + 2:
             window.pop(0)
     return bad
 
@@ -91,7 +97,7 @@ def main(argv):
         n_dpp += len(re.findall(r"^\s*v_\w+_dpp\s", text, flags=re.M))
         for kernel, no, ins, prev in check(text):
             total += 1
-            print(f"{name}:{no}: {kernel[:60]}: `{ins}` reads a register written by `{prev}` less than 2 wait states before")
+            print(f"{name}:{no}: {kernel[:60]}: `{ins}` reads a register written by `{prev}` too few wait states before")
     print(f"{n_dpp} DPP instructions checked, {total} hazards")
     return 1 if total else 0
 
