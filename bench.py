@@ -10,10 +10,17 @@ GPUs the matrix is N user blocks of 162 541 users each over the same 59 047 item
 scaling): rank r sweeps user block r and an nnz-balanced 1/N of the items, factors are
 all-gathered over RCCL after each half-sweep.  Inputs are resident in HBM before the timed
 region.  Rank 0 prints ONE JSON line.
+
+Besides the headline fields that line carries an `also` list: the same measurement (fewer steps)
+at f=128 on the same matrix, exact and conjugate-gradient, and on `c3_shard_syn` - per GPU one
+eighth of the 10 M x 1 M, 1 B-entry, f=128 matrix of BASELINE.json configs[2]; with N GPUs the
+matrix is N such blocks with user shards cut by stored entries, so N=8 is that configuration.
+`--no-also` leaves them out; `--workload/--factors/--solver` move the headline itself.
 """
 import argparse
 import json
 import os
+import platform
 import sys
 import time
 
@@ -41,30 +48,55 @@ def parse():
                          "auto = matrix for f <= 128, lock_step above")
     ap.add_argument("--accumulate", default="bf16x3", choices=["bf16x3", "fp32"],
                     help="exact solver: how the per-row normal matrix is accumulated (see include/als_hip.h)")
+    ap.add_argument("--row-kernel", default="auto", choices=["auto", "wave", "workgroup"],
+                    help="64 < f <= 128: one wavefront per row, or the row's tiles over a 4-wave workgroup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="only the headline measurement")
+    ap.add_argument("--also-steps", type=int, default=3)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work per half-sweep sample")
     return ap.parse_args()
 
 
 def build_shards(wl, world, rank, dev):
-    """This rank's shards of the weak-scaled matrix: (user CSR block, item CSR shard, bounds)."""
+    """This rank's shards of the weak-scaled matrix: (user CSR shard, item CSR shard, user bounds, item
+    bounds, N, M, nnz).  The matrix is `world` user blocks of wl["n_users"] users over the same items.
+    Block b holds wl["nnz"] entries, or - with wl["block_jitter"] - that many times 1 + jitter * (a
+    fixed pattern with zero mean), so that the blocks differ as real user populations do.  User shards
+    are the blocks themselves, or with wl["balance_users"] contiguous ranges with about equal entries."""
     from recommender_amd import data
     from recommender_amd.als import balanced_ranges
     nb, M = wl["n_users"], wl["n_items"]
     N = nb * world
+    jit = float(wl.get("block_jitter", 0.0))
+    pattern = [((b * 5) % world) / max(world - 1, 1) * 2.0 - 1.0 for b in range(world)]      # a permutation of [-1, 1]
+    mean = sum(pattern) / world
     item_counts = torch.zeros(M, dtype=torch.int64, device=dev)
+    user_counts = []
     blocks = []
     for b in range(world):
-        keys, r = data.synth_pairs(nb, M, wl["nnz"], seed=1234 + b, device=dev, item_seed=1234)
+        nnz_b = int(round(wl["nnz"] * (1.0 + jit * (pattern[b] - mean)))) if world > 1 else wl["nnz"]
+        keys, r = data.synth_pairs(nb, M, nnz_b, seed=1234 + b, device=dev, item_seed=1234)
         u = torch.div(keys, M, rounding_mode="floor"); i = keys - u * M
         item_counts += torch.bincount(i, minlength=M)
-        if b == rank:
-            U = data.csr_from_sorted_keys(keys, r, nb, M)
+        user_counts.append(torch.bincount(u, minlength=nb))
         blocks.append((u + b * nb, i, r))
         del keys
     item_ptr = np.zeros(M + 1, dtype=np.int64)
     np.cumsum(item_counts.cpu().numpy(), out=item_ptr[1:])
     ib = balanced_ranges(item_ptr, world)
+    if wl.get("balance_users") and world > 1:
+        user_ptr = np.zeros(N + 1, dtype=np.int64)
+        np.cumsum(torch.cat(user_counts).cpu().numpy(), out=user_ptr[1:])
+        ub = [int(x) for x in balanced_ranges(user_ptr, world)]
+    else:
+        ub = [nb * r for r in range(world + 1)]
+    u0, u1 = ub[rank], ub[rank + 1]
+    ks, rs = [], []
+    for (u, i, r) in blocks:                       # blocks are in user order, each sorted by (user, item)
+        m = (u >= u0) & (u < u1)
+        if bool(m.any()):
+            ks.append((u[m] - u0) * M + i[m]); rs.append(r[m])
+    U = data.csr_from_sorted_keys(torch.cat(ks), torch.cat(rs), u1 - u0, M)
     i0, i1 = int(ib[rank]), int(ib[rank + 1])
     ks, rs = [], []
     for (u, i, r) in blocks:
@@ -73,15 +105,26 @@ def build_shards(wl, world, rank, dev):
     del blocks
     tk, order = torch.sort(torch.cat(ks))
     Ut = data.csr_from_sorted_keys(tk, torch.cat(rs)[order], i1 - i0, N)
-    ub = [nb * r for r in range(world + 1)]
     return U, Ut, ub, [int(x) for x in ib], N, M, int(item_ptr[-1])
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
 
 
 def cpu_baseline(U, Ut, X0, Y0, wl, seconds):
     """The C restatement of the reference's per-row exact solve (oracle/als_ref.c, float64) on
     the host cores, on an evenly strided row sample of the SAME matrix sized to ~`seconds`
-    of work per half-sweep.  Returns nnz/s."""
-    from oracle import c_oracle
+    of work per half-sweep.  Returns nnz/s.  Beside it, once, the float32 restatement of the
+    reference's TensorFlow path on padded batches of 100 rows (oracle/als_ref.py::half_sweep_batched_f32,
+    reclibwh/core/ALS.py:160-233) on the C1-shaped matrix, timed on numpy's threads."""
+    from oracle import als_ref, c_oracle
     threads = c_oracle.max_threads()
     f, lamb, alpha = X0.shape[1], wl["lamb"], wl["alpha"]
 
@@ -107,10 +150,152 @@ def cpu_baseline(U, Ut, X0, Y0, wl, seconds):
     su = max(1, int(400 * tu / seconds)); si = max(1, int(400 * ti / seconds))
     tu, nu, ru = timed(U, Y64, X64, su)
     ti, ni, ri = timed(Ut, X64, Y64, si)
-    return {"value": (nu + ni) / (tu + ti), "unit": "nnz/s", "cores": threads, "kind": "port",
-            "sample": "oracle/als_ref.c float64: every %dth user row (%d rows, %d nnz, %.1f s) + every %dth item "
-                      "row (%d rows, %d nnz, %.1f s) of the same matrix, one half-sweep each, Gram excluded"
-                      % (su, ru, nu, tu, si, ri, ni, ti)}
+    out = {"value": (nu + ni) / (tu + ti), "unit": "nnz/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+           "host_cpus": os.cpu_count(),
+           "sample": "oracle/als_ref.c float64: every %dth user row (%d rows, %d nnz, %.1f s) + every %dth item "
+                     "row (%d rows, %d nnz, %.1f s) of the same matrix, one half-sweep each, Gram excluded"
+                     % (su, ru, nu, tu, si, ri, ni, ti)}
+    # the TF path's batched float32 form on the C1-shaped matrix (610 x 9724, f=20): one full iteration
+    try:
+        from recommender_amd import data
+        from recommender_amd.als import init_factors
+        c1 = data.WORKLOADS["c1_ml_small_syn"]
+        U1, Ut1 = data.synth_matrix(c1["n_users"], c1["n_items"], c1["nnz"], seed=1234, device="cpu")
+        Xi, Yi = init_factors(c1["n_users"] + 1, c1["n_items"] + 1, c1["f"], "tf")
+        p, c, v = (t.numpy() for t in U1)
+        pt, ct, vt = (t.numpy() for t in Ut1)
+        t = time.perf_counter()
+        X1, _ = als_ref.half_sweep_batched_f32(p, c, v, c1["n_items"], Yi, Xi, c1["lamb"], c1["alpha"], batchsize=100)
+        als_ref.half_sweep_batched_f32(pt, ct, vt, c1["n_users"], X1, Yi, c1["lamb"], c1["alpha"], batchsize=100)
+        dt = time.perf_counter() - t
+        out["batched_f32"] = {"value": 2.0 * c1["nnz"] / dt, "unit": "nnz/s", "kind": "port",
+                              "threads": "numpy/BLAS default (%d host cpus visible)" % os.cpu_count(),
+                              "sample": "oracle half_sweep_batched_f32 (padded batches of 100 rows, float32, np.linalg.inv): one "
+                                        "iteration of c1_ml_small_syn 610 x 9724, %d nnz, f=20, %.1f s" % (c1["nnz"], dt)}
+    except Exception as exc:        # the second baseline must never cost the headline line
+        out["batched_f32"] = {"error": repr(exc)}
+    return out
+
+
+class Ctx:
+    pass
+
+
+def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel, steps, warmup, shards=None):
+    """Builds (or reuses) the shards of `workload`, runs warmup + `steps` timed iterations and returns
+    (result dict, shards, host init or None).  Every per-row kernel of every half-sweep is bracketed by
+    events the library records on the launch stream (als_sweep_opts_t.tap_begin/tap_end)."""
+    from recommender_amd import data, ops
+    from recommender_amd.als import ALSEngine, init_factors
+    world, rank, dev, group = ctx.world, ctx.rank, ctx.dev, ctx.group
+    wl = dict(data.WORKLOADS[workload])
+    if f:
+        wl["f"] = f
+    f = wl["f"]
+    if shards is None:
+        shards = build_shards(wl, world, rank, dev)
+    U, Ut, ub, ib, N, M, nnz = shards
+    if wl.get("init") == "device":      # large shards: same distribution, drawn on the device
+        g = torch.Generator(device=dev); g.manual_seed(42)
+        X = torch.randn((N, f), generator=g, device=dev) / np.sqrt(f)
+        Y = torch.randn((M, f), generator=g, device=dev) / np.sqrt(f)
+        Xh = Yh = None
+    else:
+        Xh, Yh = init_factors(N, M, f, "tf")
+        X = torch.from_numpy(Xh.astype(np.float32)).to(dev)
+        Y = torch.from_numpy(Yh.astype(np.float32)).to(dev)
+    if f > 128:
+        solver = "cg"
+    csr_u = ops.DeviceCSR(U[0], U[1], U[2], (ub[rank + 1] - ub[rank], M), dev)
+    # with N user blocks an item row is N times longer: longer chunks keep the partial-sum traffic of the
+    # split rows (11 KB per chunk at f=64) small against the gather
+    csr_i = ops.DeviceCSR(Ut[0], Ut[1], Ut[2], (ib[rank + 1] - ib[rank], N), dev,
+                          chunk_nnz=2048 * (1 if world == 1 else 4))
+    eng = ALSEngine(csr_u, csr_i, X, Y, wl["lamb"], wl["alpha"], ub, ib, group, solver=solver,
+                    cg_steps=cg_steps, cg_form=cg_form)
+    cg = solver == "cg"
+    lockstep = cg and (cg_form == "lock_step" or (cg_form == "auto" and f > 128))
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    base_opts = dict(accumulate=accumulate, row_kernel=row_kernel)
+    eng.sweep_opts = lambda which: ops.sweep_opts(**base_opts)
+    for _ in range(warmup):
+        eng.step()
+    launches_per_step = (len(eng._parts()) if world > 1 else 1) + 1
+    pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * launches_per_step * steps)]
+    for e in pool:
+        e.record()          # materialise the handles
+    sync()
+    taps = {"users": [], "items": []}
+
+    def tapped(which):
+        e0, e1 = pool.pop(), pool.pop()
+        taps[which].append((e0, e1))
+        return ops.sweep_opts(tap=(e0, e1), **base_opts)
+
+    eng.sweep_opts = tapped
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.step()
+    sync()
+    dt = time.perf_counter() - t0
+    eng.sweep_opts = None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if ctx.rehearsal else dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    if int(eng.info.item()) != 0 and not os.environ.get("ALS_BENCH_IGNORE_INFO"):   # (timing-only ablation builds set it)
+        raise SystemExit("non positive definite row systems: %d" % int(eng.info.item()))
+
+    # dominant kernels: the per-row kernels of a half-sweep (gather/accumulate + solve, the long rows' combine
+    # and solve); algorithmic bytes per half-sweep = nnz*(4 col + 4 val + 4f gathered row) + n_rows*(8 rowptr
+    # + 4f written row)
+    ku = sum(e0.elapsed_time(e1) for e0, e1 in taps["users"]) / steps
+    ki = sum(e0.elapsed_time(e1) for e0, e1 in taps["items"]) / steps
+    if lockstep:
+        # per half-sweep: cg_steps+1 gather passes over the entries, plus the per-row vectors each pass
+        # reads and writes (x, r, p, z and the GEMM's operand and result)
+        sp = cg_steps
+        row_vecs = 4 + 7 * (sp - 1) + 6 + 2 * (sp + 1)
+        bytes_u = (sp + 1) * csr_u.nnz * (8 + 4 * f) + csr_u.shape[0] * (8 + 4 * f * row_vecs)
+        bytes_i = (sp + 1) * csr_i.nnz * (8 + 4 * f) + csr_i.shape[0] * (8 + 4 * f * row_vecs)
+    else:
+        bytes_u = csr_u.nnz * (8 + 4 * f) + csr_u.shape[0] * (8 + 4 * f)
+        bytes_i = csr_i.nnz * (8 + 4 * f) + csr_i.shape[0] * (8 + 4 * f)
+    achieved = (bytes_u + bytes_i) / ((ku + ki) * 1e-3) / 1e9
+    res = {
+        "workload": "%s: %d users x %d items, %d nnz, f=%d, lamb=%g, alpha=%g, %s"
+                    % (workload, N, M, nnz, f, wl["lamb"], wl["alpha"],
+                       "%d conjugate-gradient steps per row (%s)" % (cg_steps, "lock step" if lockstep else "formed matrix")
+                       if cg else "exact Cholesky solve, %s accumulate" % accumulate),
+        "nnz": nnz, "f": f, "solver": solver, "steps": steps, "seconds": dt,
+        "value": 2.0 * nnz * steps / dt, "ms_per_step": dt / steps * 1e3,
+        "kernel": ("cg half-sweep (cg_items_kernel passes + Gram GEMM)" if lockstep else
+                   "per-row kernels of the half-sweep (%s: gather/accumulate + %s; the long rows' combine and solve "
+                   "included)" % ("wide_row_items_kernel" if f > 128 else "sweep_items_kernel, row_kernel=%s" % row_kernel,
+                                  "CG on the formed matrix" if cg else "solve")),
+        "achieved": achieved, "launch_ms": {"user_sweep": ku, "item_sweep": ki},
+        "bytes_per_launch": (bytes_u + bytes_i) / 2,
+        "user_rows": csr_u.shape[0], "item_rows": csr_i.shape[0],
+    }
+    del eng, csr_u, csr_i, X, Y
+    return res, shards, (Xh, Yh, wl)
+
+
+def pmc_traffic(key):
+    """HBM bytes per launch from the PMC passes kept under profiles/ (a separate rocprofv3 run of the same
+    command: FETCH_SIZE x 2 + WRITE_SIZE); None if that configuration was not profiled."""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        return json.load(open(tpath)).get(key, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
 
 
 def main():
@@ -122,149 +307,88 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    ctx = Ctx()
     # ALS_BENCH_REHEARSAL=1: every rank on GPU 0 with gloo collectives, to walk the multi-rank code
     # path on a one-GPU box (its timings mean nothing)
-    rehearsal = bool(os.environ.get("ALS_BENCH_REHEARSAL"))
-    if rehearsal:
+    ctx.rehearsal = bool(os.environ.get("ALS_BENCH_REHEARSAL"))
+    if ctx.rehearsal:
         local = 0
         import faulthandler
-        faulthandler.dump_traceback_later(60, exit=True)      # a stuck rehearsal names where it is stuck
+        faulthandler.dump_traceback_later(int(os.environ.get("ALS_BENCH_REHEARSAL_TIMEOUT", "240")), exit=True)
     torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    group = None
+    ctx.dev = torch.device("cuda", local)
+    ctx.world, ctx.rank, ctx.group = world, rank, None
+    backend = None
     if world > 1:
-        if rehearsal:
+        backend = "gloo" if ctx.rehearsal else "nccl"
+        if ctx.rehearsal:
             torch.distributed.init_process_group("gloo")
         else:
-            torch.distributed.init_process_group("nccl", device_id=dev)
-        group = torch.distributed.group.WORLD
+            torch.distributed.init_process_group("nccl", device_id=ctx.dev)
+        ctx.group = torch.distributed.group.WORLD
 
-    from recommender_amd import data, ops
-    from recommender_amd._lib import lib
-    from recommender_amd.als import ALSEngine, init_factors
-    import ctypes
+    head, shards, (Xh, Yh, wl) = measure(ctx, args.workload, args.factors, args.solver, args.cg_steps, args.cg_form,
+                                         args.accumulate, args.row_kernel, args.steps, args.warmup)
+    f = head["f"]
+    cg = head["solver"] == "cg"
 
-    ops.set_accumulate_mode(args.accumulate)
-    wl = dict(data.WORKLOADS[args.workload])
-    if args.factors:
-        wl["f"] = args.factors
-    f = wl["f"]
-    U, Ut, ub, ib, N, M, nnz = build_shards(wl, world, rank, dev)
-    if wl.get("init") == "device":      # large shards: same distribution, drawn on the device
-        g = torch.Generator(device=dev); g.manual_seed(42)
-        X = torch.randn((N, f), generator=g, device=dev) / np.sqrt(f)
-        Y = torch.randn((M, f), generator=g, device=dev) / np.sqrt(f)
-        Xh = Yh = None
-    else:
-        Xh, Yh = init_factors(N, M, f, "tf")
-        X = torch.from_numpy(Xh.astype(np.float32)).to(dev)
-        Y = torch.from_numpy(Yh.astype(np.float32)).to(dev)
-    if wl.get("solver") and args.solver == "cholesky" and f > 128:
-        args.solver = wl["solver"]
-    csr_u = ops.DeviceCSR(U[0], U[1], U[2], (ub[rank + 1] - ub[rank], M), dev)
-    # with N user blocks an item row is N times longer: longer chunks keep the partial-sum traffic of the
-    # split rows (11 KB per chunk at f=64) small against the gather
-    csr_i = ops.DeviceCSR(Ut[0], Ut[1], Ut[2], (ib[rank + 1] - ib[rank], N), dev,
-                          chunk_nnz=2048 * (1 if world == 1 else 4))
-    eng = ALSEngine(csr_u, csr_i, X, Y, wl["lamb"], wl["alpha"], ub, ib, group, solver=args.solver,
-                    cg_steps=args.cg_steps)
-    cg = args.solver == "cg"
-    lockstep = cg and (args.cg_form == "lock_step" or (args.cg_form == "auto" and f > 128))
-    if cg and args.cg_form != "auto":
-        import functools
-        ops.half_sweep_cg = functools.partial(ops.half_sweep_cg, form=args.cg_form)
+    also = []
+    if not args.no_also:
+        plan = []
+        if args.workload == "c2_ml25m_syn" and not args.factors and args.solver == "cholesky":
+            plan.append(("c2_ml25m_syn", 128, "cholesky", shards))
+            plan.append(("c2_ml25m_syn", 128, "cg", shards))
+            plan.append(("c3_shard_syn", None, "cholesky", None))
+            plan.append(("c3_shard_syn", None, "cg", "prev"))
+        prev = None
+        for (wname, ff, solver, sh) in plan:
+            try:
+                r, prev, _ = measure(ctx, wname, ff, solver, args.cg_steps, "auto", args.accumulate, args.row_kernel,
+                                     args.also_steps, 1, shards=prev if sh == "prev" else sh)
+                also.append({"workload": r["workload"], "f": r["f"], "solver": r["solver"], "steps": r["steps"],
+                             "nnz_per_s": r["value"], "ms_per_step": r["ms_per_step"], "launch_ms": r["launch_ms"],
+                             "achieved_GBs": r["achieved"], "frac": r["achieved"] / HBM_PEAK_GBS,
+                             "algorithmic_bytes_per_launch": r["bytes_per_launch"], "kernel": r["kernel"],
+                             "rows_this_rank": {"user": r["user_rows"], "item": r["item_rows"]}})
+            except Exception as exc:            # a failing extra point must not cost the headline line
+                also.append({"workload": wname, "f": ff, "solver": solver, "error": repr(exc)})
+                prev = None
+            torch.cuda.empty_cache()
 
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        eng.step()
-    # taps: events around every launch of the gather/accumulate kernel, on the launch stream
-    # (the user sweep is several launches when its all-gather is overlapped chunk by chunk)
-    launches_per_step = (len(eng._parts()) if world > 1 else 1) + 1
-    pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * launches_per_step * args.steps)]
-    for e in pool:
-        e.record()          # materialise the handles
-    sync()
-    taps = {"users": [], "items": []}
-
-    def tap(which):
-        e0, e1 = pool.pop(), pool.pop()
-        if lockstep:  # several kernels per half-sweep: events around the whole call, on the launch stream
-            e0.record()
-        else:       # exact path: the library records the events around the one gather/accumulate/solve kernel
-            lib.als_profile_tap_next_sweep(ctypes.c_void_p(e0.cuda_event), ctypes.c_void_p(e1.cuda_event))
-        taps[which].append((e0, e1))
-
-    def tap_end(which):
-        if lockstep:
-            taps[which][-1][1].record()
-
-    eng.post_sweep_hook = tap_end
-    eng.pre_sweep_hook = tap
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.step()
-    sync()
-    dt = time.perf_counter() - t0
-    eng.pre_sweep_hook = eng.post_sweep_hook = None
+    ranks = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    if int(eng.info.item()) != 0 and not os.environ.get("ALS_BENCH_IGNORE_INFO"):   # (timing-only ablation builds set it)
-        raise SystemExit("non positive definite row systems: %d" % int(eng.info.item()))
-
-    # dominant kernel: the per-row gather/accumulate(+solve) kernel; algorithmic bytes per launch =
-    # nnz*(4 col + 4 val + 4f gathered row) + n_rows*(8 rowptr + 4f written row)
-    ku = sum(e0.elapsed_time(e1) for e0, e1 in taps["users"]) / args.steps
-    ki = sum(e0.elapsed_time(e1) for e0, e1 in taps["items"]) / args.steps
-    if lockstep:
-        # per half-sweep: cg_steps+1 gather passes over the entries, plus the per-row vectors each pass
-        # reads and writes (x, r, p, z and the GEMM's operand and result): see DESIGN.md
-        sp = args.cg_steps
-        row_vecs = 4 + 7 * (sp - 1) + 6 + 2 * (sp + 1)
-        bytes_u = (sp + 1) * csr_u.nnz * (8 + 4 * f) + csr_u.shape[0] * (8 + 4 * f * row_vecs)
-        bytes_i = (sp + 1) * csr_i.nnz * (8 + 4 * f) + csr_i.shape[0] * (8 + 4 * f * row_vecs)
-    else:
-        bytes_u = csr_u.nnz * (8 + 4 * f) + csr_u.shape[0] * (8 + 4 * f)
-        bytes_i = csr_i.nnz * (8 + 4 * f) + csr_i.shape[0] * (8 + 4 * f)
-    achieved = (bytes_u + bytes_i) / ((ku + ki) * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(args.workload + "_f%d" % f + ("_cg" if cg else ""), {}).get("hbm_bytes_per_launch")
-            if args.accumulate != "bf16x3":
-                traffic = None
-        except Exception:
-            traffic = None
+        mine = {"rank": rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name(),
+                "uuid": str(getattr(torch.cuda.get_device_properties(ctx.dev), "uuid", ""))}
+        ranks = [None] * world
+        torch.distributed.all_gather_object(ranks, mine)
 
     if rank == 0:
+        tkey = args.workload + "_f%d" % f + ("_cg" if cg else "") + ("_fp32mode" if args.accumulate == "fp32" else "")
+        traffic = pmc_traffic(tkey)
         out = {
             "metric": "ALS nnz/sec (2*nnz per iteration; iterations/sec in iters_per_s)",
-            "value": 2.0 * nnz * args.steps / dt, "unit": "nnz/s", "iters_per_s": args.steps / dt,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "value": head["value"], "unit": "nnz/s", "iters_per_s": args.steps / head["seconds"],
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %d users x %d items, %d nnz, f=%d, lamb=%g, alpha=%g, %s"
-                                   % (args.workload, N, M, nnz, f, wl["lamb"], wl["alpha"],
-                                      "%d conjugate-gradient steps per row" % args.cg_steps if cg
-                                      else "exact Cholesky solve, %s accumulate" % args.accumulate),
+            "config": {"workload": head["workload"],
                        "parallelism": "dp%d (user/item row shards, all-gather of factors)" % world},
-            "roofline": {"bound": "hbm", "kernel": "cg half-sweep (cg_items_kernel passes + Gram GEMM)" if lockstep
-                         else "%s (per-row gather/accumulate + %s)" % ("wide_row_items_kernel" if f > 128 else "sweep_items_kernel",
-                                                                       "CG on the formed matrix" if cg else "solve"),
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "avg_launch_ms": (ku + ki) / 2,
-                         "launch_ms": {"user_sweep": ku, "item_sweep": ki},
-                         "algorithmic_bytes_per_launch": (bytes_u + bytes_i) / 2},
+            "roofline": {"bound": "hbm", "kernel": head["kernel"],
+                         "achieved": head["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": head["achieved"] / HBM_PEAK_GBS,
+                         "traffic": traffic,
+                         "traffic_source": ("profiles/pmc_traffic.json[%s]: a separate rocprofv3 --pmc run of this "
+                                            "command (FETCH_SIZE x 2 + WRITE_SIZE per launch), not measured in this run" % tkey)
+                         if traffic is not None else None,
+                         "avg_launch_ms": (head["launch_ms"]["user_sweep"] + head["launch_ms"]["item_sweep"]) / 2,
+                         "launch_ms": head["launch_ms"],
+                         "algorithmic_bytes_per_launch": head["bytes_per_launch"]},
         }
+        if world > 1:
+            out["distributed"] = {"backend": backend, "world_size": torch.distributed.get_world_size(), "ranks": ranks}
+        if also:
+            out["also"] = also
         if world == 1 and not args.no_cpu_baseline and Xh is not None:
-            out["cpu_baseline"] = cpu_baseline(U, Ut, Xh, Yh, wl, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(shards[0], shards[1], Xh, Yh, wl, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -49,18 +49,37 @@ const char *als_last_error_string(void);
 /* Library ABI version (bumped on any signature change). */
 int32_t als_abi_version(void);
 
-/* How the exact half-sweep forms  sum_j alpha r_uj y_j y_j^T  for 16 < f <= 128 (process-wide
- * setting, no reference counterpart):
- *   ALS_ACCUMULATE_BF16X3 (default)  every value is cut exactly into three bf16 pieces and the six
- *       significant piece products run on the bf16 matrix cores, accumulated in float32; error
- *       at the level of float32 rounding (the dropped products are < 2^-23 of each term);
- *   ALS_ACCUMULATE_FP32              float32 matrix-core fma chain in CSR order (v_mfma_f32_16x16x4_f32).
- * Both are deterministic and independent of the launch geometry.  f <= 16 always uses FP32, as
- * does the Gram. */
-#define ALS_ACCUMULATE_FP32 0
+/* Per-call options of the half-sweeps (no reference counterpart).  NULL, or a zeroed struct, selects
+ * every default; nothing here is kept after the call returns and the library holds no settings
+ * of its own, so concurrent callers do not affect each other.
+ *   accumulate  how  sum_j alpha r_uj y_j y_j^T  is formed for 16 < f <= 128:
+ *       ALS_ACCUMULATE_BF16X3 (default)  every value is cut exactly into three bf16 pieces and the six
+ *           significant piece products run on the bf16 matrix cores, accumulated in float32; error
+ *           at the level of float32 rounding (the dropped products are < 2^-23 of each term);
+ *       ALS_ACCUMULATE_FP32              float32 matrix-core fma chain in CSR order (v_mfma_f32_16x16x4_f32).
+ *       Both are deterministic and independent of the launch geometry.  f <= 16 always uses FP32,
+ *       as does the Gram.
+ *   row_kernel  which per-row kernel handles 64 < f <= 128 (results agree to float32 rounding, each
+ *       is reproducible bit for bit):
+ *       ALS_ROW_KERNEL_WAVE       one wavefront owns a row's whole matrix (144 accumulator registers);
+ *       ALS_ROW_KERNEL_WORKGROUP  the row's 36 tiles are spread over the 4 wavefronts of a workgroup,
+ *                                 operands shared through LDS (bf16 x 3 accumulate only);
+ *       ALS_ROW_KERNEL_AUTO       the library's choice.
+ *   tap_begin / tap_end  two hipEvent_t handles, or both NULL: recorded on `stream` immediately before
+ *       the first and after the last per-row kernel of the call (benchmarks time the kernels with
+ *       them; the final |delta| reduction lies outside). */
+#define ALS_ACCUMULATE_DEFAULT 0
 #define ALS_ACCUMULATE_BF16X3 1
-int32_t als_set_accumulate_mode(int32_t mode);
-int32_t als_get_accumulate_mode(void);
+#define ALS_ACCUMULATE_FP32 2
+#define ALS_ROW_KERNEL_AUTO 0
+#define ALS_ROW_KERNEL_WAVE 1
+#define ALS_ROW_KERNEL_WORKGROUP 2
+typedef struct {
+    int32_t accumulate;
+    int32_t row_kernel;
+    void *tap_begin;
+    void *tap_end;
+} als_sweep_opts_t;
 
 /* ------------------------------------------------------------------------------------
  * Row schedule ("plan") - host-side, CPU only, built once per CSR matrix.
@@ -149,6 +168,7 @@ int32_t als_gram_finalize_f32(const float *super_in, int64_t n_super, int32_t f,
  * absdiff_out    [device] one double, or NULL.
  * info_out       [device] one int32, or NULL: incremented once per row whose system
  *                was not positive definite in float32 (that row's x is then NaN).
+ * opts           [host] per-call options, or NULL for the defaults.
  * ------------------------------------------------------------------------------------ */
 size_t als_half_sweep_workspace_bytes(int64_t n_rows, int64_t n_slots, int32_t f);
 int32_t als_half_sweep_csr_f32(const int64_t *rowptr, const int32_t *col, const float *val, int64_t n_rows,
@@ -156,8 +176,8 @@ int32_t als_half_sweep_csr_f32(const int64_t *rowptr, const int32_t *col, const 
                                const als_long_row_t *long_rows, int64_t n_long, int64_t n_slots,
                                int32_t chunk_nnz, const float *Yopp, int64_t n_opp, int64_t ldy,
                                const float *gram_tiles, int32_t f, float alpha, float *Xown, int64_t ldx,
-                               double *absdiff_out, int32_t *info_out, void *workspace, size_t ws_bytes,
-                               void *stream);
+                               double *absdiff_out, int32_t *info_out, const als_sweep_opts_t *opts,
+                               void *workspace, size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Conjugate-gradient half-sweep, 1 <= f <= ALS_MAX_FACTORS.  Same normal equations and same
@@ -197,7 +217,7 @@ int32_t als_half_sweep_cg_f32(const int64_t *rowptr, const int32_t *col, const f
                               int32_t chunk_nnz, const float *Yopp, int64_t n_opp, int64_t ldy, const float *gram,
                               const float *gram_tiles, float lamb, int32_t f, float alpha, int32_t cg_steps,
                               int32_t form, float *Xown, int64_t ldx, double *absdiff_out, int32_t *info_out,
-                              void *workspace, size_t ws_bytes, void *stream);
+                              const als_sweep_opts_t *opts, void *workspace, size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Scoring - replaces ALSTrainer.predict + SimpleMFRecAlgo.recommend
@@ -249,12 +269,6 @@ int32_t als_predict_pairs_f32(const float *X, int64_t ldx, const float *Y, int64
                               const int64_t *i, int64_t n, int32_t f, float *out, void *stream);
 int32_t als_normalize_rows_f32(const float *E, int64_t lde, int64_t n, int32_t f, float *out, int64_t ldo,
                                void *stream);
-
-/* Profiling tap (no reference counterpart; for benchmarks): the next
- * als_half_sweep_csr_f32 call made by the calling thread records the two hipEvent_t
- * handles on its stream immediately before and after its per-row gather/accumulate
- * kernel, then forgets them.  Pass NULLs to clear. */
-int32_t als_profile_tap_next_sweep(void *ev_begin, void *ev_end);
 
 #ifdef __cplusplus
 }

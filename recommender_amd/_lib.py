@@ -22,7 +22,8 @@ GRAM_SUPER_ROWS = 65536
 MAX_FACTORS = 256
 MAX_FACTORS_EXACT = 128
 GRAM_WIDE_CHUNK_ROWS = 4096
-ACCUMULATE_FP32, ACCUMULATE_BF16X3 = 0, 1
+ACCUMULATE_MODES = {"default": 0, "bf16x3": 1, "fp32": 2}
+ROW_KERNELS = {"auto": 0, "wave": 1, "workgroup": 2}
 CG_FORMS = {"auto": 0, "lock_step": 1, "matrix": 2}
 
 c_i32, c_i64, c_f32, c_sz, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
@@ -31,8 +32,6 @@ c_i32, c_i64, c_f32, c_sz, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 SIGNATURES = {
     "als_last_error_string": (ctypes.c_char_p, []),
     "als_abi_version": (c_i32, []),
-    "als_set_accumulate_mode": (c_i32, [c_i32]),
-    "als_get_accumulate_mode": (c_i32, []),
     "als_plan_count": (c_i32, [c_vp, c_i64, c_i32, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "als_plan_fill": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp]),
     "als_gram_tiles_bytes": (c_sz, [c_i32]),
@@ -40,7 +39,6 @@ SIGNATURES = {
     "als_gram_f32": (c_i32, [c_vp, c_i64, c_i32, c_i64, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "als_gram_partials_f32": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i64, c_vp, c_vp, c_sz, c_vp]),
     "als_gram_finalize_f32": (c_i32, [c_vp, c_i64, c_i32, c_f32, c_vp, c_vp, c_vp]),
-    "als_profile_tap_next_sweep": (c_i32, [c_vp, c_vp]),
     "als_scores_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_vp]),
     "als_topk_rows_f32": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "als_recommend_topk_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32]),
@@ -52,11 +50,16 @@ SIGNATURES = {
     "als_half_sweep_cg_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32]),
     "als_half_sweep_cg_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32,
                                       c_vp, c_i64, c_i64, c_vp, c_vp, c_f32, c_i32, c_f32, c_i32, c_i32, c_vp, c_i64, c_vp,
-                                      c_vp, c_vp, c_sz, c_vp]),
+                                      c_vp, c_vp, c_vp, c_sz, c_vp]),
     "als_half_sweep_csr_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32,
-                                       c_vp, c_i64, c_i64, c_vp, c_i32, c_f32, c_vp, c_i64, c_vp, c_vp, c_vp, c_sz,
+                                       c_vp, c_i64, c_i64, c_vp, c_i32, c_f32, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz,
                                        c_vp]),
 }
+
+
+class SweepOpts(ctypes.Structure):
+    """als_sweep_opts_t of include/als_hip.h."""
+    _fields_ = [("accumulate", c_i32), ("row_kernel", c_i32), ("tap_begin", c_vp), ("tap_end", c_vp)]
 
 
 class AlsHipError(RuntimeError):

@@ -77,14 +77,17 @@ def als_update_cache(Y, lamb, cache=None, group=None, backend=ops):
     return backend.gram_finalize(torch.cat(parts, 0).to(Y.device).contiguous(), f, lamb, out=cache)
 
 
-def run_als_epoch(csr, X, Y, cache, alpha, absdiff=None, info=None, backend=ops, cg_steps=0):
+def run_als_epoch(csr, X, Y, cache, alpha, absdiff=None, info=None, backend=ops, cg_steps=0, cg_form="auto",
+                  opts=None):
     """One half-sweep over the rows of `csr`: re-solves those rows of X in place against the
     fixed Y and its cache (ALS.py:201-233).  Returns the device scalar sum|X_old - X_new|
     (float64); the reference's return value is that divided by n_rows * f.
-    cg_steps > 0: that many conjugate-gradient steps per row instead of the exact solve."""
+    cg_steps > 0: that many conjugate-gradient steps per row instead of the exact solve.
+    opts: ops.sweep_opts(...) - per-call kernel options (accumulate mode, timing taps)."""
     if cg_steps:
-        return backend.half_sweep_cg(csr, Y, cache, X, alpha, cg_steps, absdiff=absdiff, info=info)
-    return backend.half_sweep(csr, Y, cache, X, alpha, absdiff=absdiff, info=info)
+        return backend.half_sweep_cg(csr, Y, cache, X, alpha, cg_steps, absdiff=absdiff, info=info, form=cg_form,
+                                     opts=opts)
+    return backend.half_sweep(csr, Y, cache, X, alpha, absdiff=absdiff, info=info, opts=opts)
 
 
 def _host_staged(T, group):
@@ -150,7 +153,7 @@ class ALSEngine:
     """
 
     def __init__(self, csr_users, csr_items, X, Y, lamb, alpha, user_bounds=None, item_bounds=None, group=None,
-                 backend=ops, overlap_chunks=None, solver="auto", cg_steps=3):
+                 backend=ops, overlap_chunks=None, solver="auto", cg_steps=3, cg_form="auto"):
         self.group = group
         self.backend = backend      # the HIP operators; tests inject a CPU stand-in to exercise the sharding logic
         self.world = torch.distributed.get_world_size(group) if group is not None else 1
@@ -182,14 +185,14 @@ class ALSEngine:
         self.cg_steps = int(cg_steps) if solver == "cg" else 0
         if solver == "cg" and self.cg_steps < 1:
             raise ValueError("cg_steps must be >= 1")
+        self.cg_form = cg_form
+        self.sweep_opts = None         # callable("users" | "items") -> ops.sweep_opts(...) for that launch, or None
         self.cache_Y = backend.GramCache(self.f, lamb, X.device)
         self.cache_X = backend.GramCache(self.f, lamb, X.device)
         self._dX = torch.zeros(1, dtype=torch.float64, device=X.device)
         self._dY = torch.zeros(1, dtype=torch.float64, device=X.device)
         self.info = torch.zeros(1, dtype=torch.int32, device=X.device)
         self.trace = []
-        self.pre_sweep_hook = None     # callable("users" | "items"), run just before each sweep launch
-        self.post_sweep_hook = None    # the same, just after it
         # Multi-GPU: the user sweep runs as `overlap_chunks` row chunks; the all-gather of chunk c
         # runs on a side stream beside the sweep of chunk c+1, so only the last chunk's exchange is
         # exposed.  A row's result does not depend on which launch computes it, so factors are
@@ -225,10 +228,8 @@ class ALSEngine:
         done = []
         for c, (r0, r1, csr, dbuf) in enumerate(parts):
             if csr is not None:
-                if self.pre_sweep_hook: self.pre_sweep_hook("users")
                 run_als_epoch(csr, self.X[u0 + r0:u0 + r1], self.Y, self.cache_Y, self.alpha, dbuf, self.info,
-                              self.backend, self.cg_steps)
-                if self.post_sweep_hook: self.post_sweep_hook("users")
+                              self.backend, self.cg_steps, self.cg_form, self.sweep_opts("users") if self.sweep_opts else None)
             else:
                 dbuf.zero_()
             if not chunked:
@@ -259,10 +260,8 @@ class ALSEngine:
         self._sweep_users()
         als_update_cache(self.X, self.lamb, self.cache_X, self.group, self.backend)
         if i1 > i0:
-            if self.pre_sweep_hook: self.pre_sweep_hook("items")
             run_als_epoch(self.csr_items, self.Y[i0:i1], self.X, self.cache_X, self.alpha, self._dY, self.info,
-                          self.backend, self.cg_steps)
-            if self.post_sweep_hook: self.post_sweep_hook("items")
+                          self.backend, self.cg_steps, self.cg_form, self.sweep_opts("items") if self.sweep_opts else None)
         if self.world > 1:
             _all_gather_rows(self.Y[: self.n_items], self.item_bounds, self.rank, self.group)
 

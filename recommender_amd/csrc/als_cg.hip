@@ -30,14 +30,16 @@ int32_t als_half_sweep_tiles_(const int64_t *rowptr, const int32_t *col, const f
                               const als_long_row_t *long_rows, int64_t n_long, int64_t n_slots, int32_t chunk_nnz,
                               const float *Yopp, int64_t n_opp, int64_t ldy, const float *gram_tiles, int32_t f,
                               float alpha, int32_t cg_steps, float *Xown, int64_t ldx, double *absdiff_out,
-                              int32_t *info_out, void *workspace, size_t ws_bytes, void *stream);          // als_kernels.hip
+                              int32_t *info_out, const als_sweep_opts_t *opts, void *workspace, size_t ws_bytes,
+                              void *stream);                                                                // als_kernels.hip
 size_t als_half_sweep_wide_workspace_bytes_(int64_t n_rows, int64_t n_slots);                              // als_kernels.hip
 int32_t als_half_sweep_wide_(const int64_t *rowptr, const int32_t *col, const float *val, int64_t n_rows,
                              const int64_t *row_ids, const als_item_t *items, int64_t n_items,
                              const als_long_row_t *long_rows, int64_t n_long, int64_t n_slots, int32_t chunk_nnz,
                              const float *Yopp, int64_t n_opp, int64_t ldy, const float *gram_tiles, float lamb, int32_t f,
                              float alpha, int32_t cg_steps, float *Xown, int64_t ldx, double *absdiff_out,
-                             int32_t *info_out, void *workspace, size_t ws_bytes, void *stream);           // als_kernels.hip
+                             int32_t *info_out, const als_sweep_opts_t *opts, void *workspace, size_t ws_bytes,
+                             void *stream);                                                                 // als_kernels.hip
 
 #define ALS_HIP_CHECK3(expr)                                                                      \
     do {                                                                                          \
@@ -584,8 +586,8 @@ int32_t als_half_sweep_cg_f32(const int64_t *rowptr, const int32_t *col, const f
                               const als_long_row_t *long_rows, int64_t n_long, int64_t n_slots, int32_t chunk_nnz,
                               const float *Yopp, int64_t n_opp, int64_t ldy, const float *gram, const float *gram_tiles,
                               float lamb, int32_t f, float alpha, int32_t cg_steps, int32_t form, float *Xown,
-                              int64_t ldx, double *absdiff_out, int32_t *info_out, void *workspace, size_t ws_bytes,
-                              void *stream) {
+                              int64_t ldx, double *absdiff_out, int32_t *info_out, const als_sweep_opts_t *opts,
+                              void *workspace, size_t ws_bytes, void *stream) {
     if (cg_steps < 1 || cg_steps > 1024) return als_fail_(ALS_ERR_INVALID_ARG, "cg_steps=%d outside [1, 1024]", cg_steps);
     if (form != ALS_CG_FORM_AUTO && form != ALS_CG_FORM_LOCK_STEP && form != ALS_CG_FORM_MATRIX)
         return als_fail_(ALS_ERR_INVALID_ARG, "als_half_sweep_cg_f32: unknown form %d", form);
@@ -597,11 +599,11 @@ int32_t als_half_sweep_cg_f32(const int64_t *rowptr, const int32_t *col, const f
     if (gram_tiles && f <= ALS_MAX_FACTORS_EXACT)      // one gather pass: form the row's matrix, iterate in registers
         return als_half_sweep_tiles_(rowptr, col, val, n_rows, row_ids, items, n_items, long_rows, n_long, n_slots,
                                      chunk_nnz, Yopp, n_opp, ldy, gram_tiles, f, alpha, cg_steps, Xown, ldx, absdiff_out,
-                                     info_out, workspace, ws_bytes, stream);
+                                     info_out, opts, workspace, ws_bytes, stream);
     if (gram_tiles && f <= ALS_MAX_FACTORS)            // the same with the row's tiles spread over 4 waves
         return als_half_sweep_wide_(rowptr, col, val, n_rows, row_ids, items, n_items, long_rows, n_long, n_slots, chunk_nnz,
                                     Yopp, n_opp, ldy, gram_tiles, lamb, f, alpha, cg_steps, Xown, ldx, absdiff_out, info_out,
-                                    workspace, ws_bytes, stream);
+                                    opts, workspace, ws_bytes, stream);
     if (!rowptr || !col || !val || !items || !Yopp || !gram || !Xown || !workspace)
         return als_fail_(ALS_ERR_INVALID_ARG, "als_half_sweep_cg_f32: null pointer");
     if (n_rows < 1 || n_rows > INT32_MAX || n_items < n_rows || n_long < 0 || n_slots < 0 || n_opp < 1)
@@ -618,6 +620,9 @@ int32_t als_half_sweep_cg_f32(const int64_t *rowptr, const int32_t *col, const f
         return als_fail_(ALS_ERR_WORKSPACE, "cg workspace too small: %zu < %zu", ws_bytes,
                          als_half_sweep_cg_workspace_bytes(n_rows, n_slots, f));
     hipStream_t st = (hipStream_t)stream;
+    if (opts && ((opts->tap_begin == nullptr) != (opts->tap_end == nullptr)))
+        return als_fail_(ALS_ERR_INVALID_ARG, "als_sweep_opts_t: pass both tap events or neither");
+    if (opts && opts->tap_begin) ALS_HIP_CHECK3(hipEventRecord((hipEvent_t)opts->tap_begin, st));
     const int64_t ldw = (int64_t)align_up((size_t)f, 4);
     char *ws = (char *)workspace;
     const size_t vec_bytes = align_up((size_t)n_rows * ldw * sizeof(float), 256);
@@ -663,6 +668,7 @@ int32_t als_half_sweep_cg_f32(const int64_t *rowptr, const int32_t *col, const f
         rc = cg_pass(p, last ? CG_LAST : CG_ITER, vec, n_items, n_long, st);
         if (rc) return rc;
     }
+    if (opts && opts->tap_end) ALS_HIP_CHECK3(hipEventRecord((hipEvent_t)opts->tap_end, st));
     if (absdiff_out) return als_sum_rowdiff_(p.rowdiff, n_rows, diff_partials, absdiff_out, st);
     return ALS_OK;
 }

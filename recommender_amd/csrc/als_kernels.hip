@@ -21,7 +21,6 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -36,7 +35,8 @@ int32_t als_half_sweep_tiles_(const int64_t *rowptr, const int32_t *col, const f
                               const als_long_row_t *long_rows, int64_t n_long, int64_t n_slots, int32_t chunk_nnz,
                               const float *Yopp, int64_t n_opp, int64_t ldy, const float *gram_tiles, int32_t f,
                               float alpha, int32_t cg_steps, float *Xown, int64_t ldx, double *absdiff_out,
-                              int32_t *info_out, void *workspace, size_t ws_bytes, void *stream);
+                              int32_t *info_out, const als_sweep_opts_t *opts, void *workspace, size_t ws_bytes,
+                              void *stream);
 // wide Gram (128 < f <= 256), als_cg.hip
 size_t als_gram_wide_tiles_bytes_(int f);
 size_t als_gram_wide_workspace_bytes_(int64_t n, int f);
@@ -49,8 +49,6 @@ namespace {
 
 // ----------------------------------------------------------------------------- errors
 thread_local char g_err[512] = "";
-thread_local hipEvent_t g_tap_begin = nullptr, g_tap_end = nullptr;
-std::atomic<int> g_accumulate_mode{ALS_ACCUMULATE_BF16X3};   // process wide; read once per launch
 
 int fail(int code, const char *fmt, ...) {
     va_list ap;
@@ -990,16 +988,37 @@ static int32_t gram_partials_impl(const float *Y, int64_t row_begin, int64_t row
     return ALS_OK;
 }
 
+// Per-call options with the defaults filled in (opts may be NULL).
+struct SweepOpts {
+    bool split;                 // bf16 x 3 accumulate (where the kernel has it)
+    int row_kernel;             // ALS_ROW_KERNEL_*
+    hipEvent_t tap0, tap1;
+};
+inline int32_t read_opts(const als_sweep_opts_t *o, SweepOpts &out) {
+    out.split = true; out.row_kernel = ALS_ROW_KERNEL_AUTO; out.tap0 = out.tap1 = nullptr;
+    if (!o) return ALS_OK;
+    if (o->accumulate != ALS_ACCUMULATE_DEFAULT && o->accumulate != ALS_ACCUMULATE_FP32 &&
+        o->accumulate != ALS_ACCUMULATE_BF16X3)
+        return fail(ALS_ERR_INVALID_ARG, "als_sweep_opts_t: unknown accumulate mode %d", o->accumulate);
+    if (o->row_kernel != ALS_ROW_KERNEL_AUTO && o->row_kernel != ALS_ROW_KERNEL_WAVE && o->row_kernel != ALS_ROW_KERNEL_WORKGROUP)
+        return fail(ALS_ERR_INVALID_ARG, "als_sweep_opts_t: unknown row_kernel %d", o->row_kernel);
+    if ((o->tap_begin == nullptr) != (o->tap_end == nullptr))
+        return fail(ALS_ERR_INVALID_ARG, "als_sweep_opts_t: pass both tap events or neither");
+    out.split = o->accumulate != ALS_ACCUMULATE_FP32;
+    out.row_kernel = o->row_kernel;
+    out.tap0 = (hipEvent_t)o->tap_begin;
+    out.tap1 = (hipEvent_t)o->tap_end;
+    return ALS_OK;
+}
+
 template <int VW>
 static int32_t half_sweep_impl(const SweepParams &p, int64_t n_rows, int64_t n_items, int64_t n_long,
-                               double *absdiff_out, double *diff_partials, bool vec, hipStream_t st) {
-    hipEvent_t tap0 = g_tap_begin, tap1 = g_tap_end;
-    g_tap_begin = g_tap_end = nullptr;
+                               double *absdiff_out, double *diff_partials, bool vec, const SweepOpts &o, hipStream_t st) {
+    if (o.tap0) ALS_HIP_CHECK(hipEventRecord(o.tap0, st));
     if (n_items > 0) {
-        if (tap0) ALS_HIP_CHECK(hipEventRecord(tap0, st));
         const dim3 grid((unsigned)n_items), block(64);
         constexpr bool CAN_SPLIT = VW >= 4;
-        const bool split = CAN_SPLIT && g_accumulate_mode == ALS_ACCUMULATE_BF16X3;
+        const bool split = CAN_SPLIT && o.split;
         if (vec && p.f == Geo<VW>::FPAD) {
             if (split) hipLaunchKernelGGL((sweep_items_kernel<VW, true, true, CAN_SPLIT>), grid, block, 0, st, p);
             else hipLaunchKernelGGL((sweep_items_kernel<VW, true, true, false>), grid, block, 0, st, p);
@@ -1011,7 +1030,6 @@ static int32_t half_sweep_impl(const SweepParams &p, int64_t n_rows, int64_t n_i
             else hipLaunchKernelGGL((sweep_items_kernel<VW, false, false, false>), grid, block, 0, st, p);
         }
         ALS_HIP_CHECK(hipGetLastError());
-        if (tap1) ALS_HIP_CHECK(hipEventRecord(tap1, st));
     }
     if (n_long > 0) {
         const int elems = Geo<VW>::PQ * 64;
@@ -1021,6 +1039,7 @@ static int32_t half_sweep_impl(const SweepParams &p, int64_t n_rows, int64_t n_i
         hipLaunchKernelGGL(sweep_long_rows_kernel<VW>, dim3((unsigned)n_long), dim3(64), 0, st, p);
         ALS_HIP_CHECK(hipGetLastError());
     }
+    if (o.tap1) ALS_HIP_CHECK(hipEventRecord(o.tap1, st));      // every per-row kernel of the half-sweep lies between the taps
     if (absdiff_out) return als_sum_rowdiff_(p.rowdiff, n_rows, diff_partials, absdiff_out, st);
     return ALS_OK;
 }
@@ -1052,21 +1071,7 @@ extern "C" {
 
 const char *als_last_error_string(void) { return g_err; }
 
-int32_t als_profile_tap_next_sweep(void *ev_begin, void *ev_end) {
-    if ((ev_begin == nullptr) != (ev_end == nullptr)) return fail(ALS_ERR_INVALID_ARG, "pass both events or neither");
-    g_tap_begin = (hipEvent_t)ev_begin;
-    g_tap_end = (hipEvent_t)ev_end;
-    return ALS_OK;
-}
-int32_t als_abi_version(void) { return 3; }
-
-int32_t als_set_accumulate_mode(int32_t mode) {
-    if (mode != ALS_ACCUMULATE_FP32 && mode != ALS_ACCUMULATE_BF16X3)
-        return fail(ALS_ERR_INVALID_ARG, "als_set_accumulate_mode: unknown mode %d", mode);
-    g_accumulate_mode = mode;
-    return ALS_OK;
-}
-int32_t als_get_accumulate_mode(void) { return g_accumulate_mode; }
+int32_t als_abi_version(void) { return 4; }
 
 // ----------------------------------------------------------------------------- plan
 int32_t als_plan_count(const int64_t *rowptr, int64_t n_rows, int32_t chunk_nnz, int64_t *n_items, int64_t *n_long,
@@ -1213,10 +1218,10 @@ int32_t als_half_sweep_csr_f32(const int64_t *rowptr, const int32_t *col, const 
                                const als_long_row_t *long_rows, int64_t n_long, int64_t n_slots, int32_t chunk_nnz,
                                const float *Yopp, int64_t n_opp, int64_t ldy, const float *gram_tiles, int32_t f,
                                float alpha, float *Xown, int64_t ldx, double *absdiff_out, int32_t *info_out,
-                               void *workspace, size_t ws_bytes, void *stream) {
+                               const als_sweep_opts_t *opts, void *workspace, size_t ws_bytes, void *stream) {
     return als_half_sweep_tiles_(rowptr, col, val, n_rows, row_ids, items, n_items, long_rows, n_long, n_slots, chunk_nnz,
-                                 Yopp, n_opp, ldy, gram_tiles, f, alpha, 0, Xown, ldx, absdiff_out, info_out, workspace,
-                                 ws_bytes, stream);
+                                 Yopp, n_opp, ldy, gram_tiles, f, alpha, 0, Xown, ldx, absdiff_out, info_out, opts,
+                                 workspace, ws_bytes, stream);
 }
 
 }  // extern "C"
@@ -1228,7 +1233,10 @@ int32_t als_half_sweep_tiles_(const int64_t *rowptr, const int32_t *col, const f
                               const als_long_row_t *long_rows, int64_t n_long, int64_t n_slots, int32_t chunk_nnz,
                               const float *Yopp, int64_t n_opp, int64_t ldy, const float *gram_tiles, int32_t f,
                               float alpha, int32_t cg_steps, float *Xown, int64_t ldx, double *absdiff_out,
-                              int32_t *info_out, void *workspace, size_t ws_bytes, void *stream) {
+                              int32_t *info_out, const als_sweep_opts_t *opts, void *workspace, size_t ws_bytes,
+                              void *stream) {
+    SweepOpts so;
+    if (const int32_t rc = read_opts(opts, so)) return rc;
     if (!rowptr || !items || !Yopp || !gram_tiles || !Xown || !workspace)
         return fail(ALS_ERR_INVALID_ARG, "als_half_sweep_csr_f32: null pointer");
     if (n_rows < 1 || n_rows > INT32_MAX || n_items < n_rows || n_long < 0 || n_slots < 0 || n_opp < 1)
@@ -1265,10 +1273,10 @@ int32_t als_half_sweep_tiles_(const int64_t *rowptr, const int32_t *col, const f
     const bool vec = vec_ok(Yopp, ldy, f, n_opp);
     hipStream_t st = (hipStream_t)stream;
     switch (vw) {
-        case 1: return half_sweep_impl<1>(p, n_rows, n_items, n_long, absdiff_out, diff_partials, vec, st);
-        case 2: return half_sweep_impl<2>(p, n_rows, n_items, n_long, absdiff_out, diff_partials, vec, st);
-        case 4: return half_sweep_impl<4>(p, n_rows, n_items, n_long, absdiff_out, diff_partials, vec, st);
-        default: return half_sweep_impl<8>(p, n_rows, n_items, n_long, absdiff_out, diff_partials, vec, st);
+        case 1: return half_sweep_impl<1>(p, n_rows, n_items, n_long, absdiff_out, diff_partials, vec, so, st);
+        case 2: return half_sweep_impl<2>(p, n_rows, n_items, n_long, absdiff_out, diff_partials, vec, so, st);
+        case 4: return half_sweep_impl<4>(p, n_rows, n_items, n_long, absdiff_out, diff_partials, vec, so, st);
+        default: return half_sweep_impl<8>(p, n_rows, n_items, n_long, absdiff_out, diff_partials, vec, so, st);
     }
 }
 
@@ -1284,7 +1292,10 @@ int32_t als_half_sweep_wide_(const int64_t *rowptr, const int32_t *col, const fl
                              const als_long_row_t *long_rows, int64_t n_long, int64_t n_slots, int32_t chunk_nnz,
                              const float *Yopp, int64_t n_opp, int64_t ldy, const float *gram_tiles, float lamb, int32_t f,
                              float alpha, int32_t cg_steps, float *Xown, int64_t ldx, double *absdiff_out,
-                             int32_t *info_out, void *workspace, size_t ws_bytes, void *stream) {
+                             int32_t *info_out, const als_sweep_opts_t *opts, void *workspace, size_t ws_bytes,
+                             void *stream) {
+    SweepOpts so;
+    if (const int32_t rc = read_opts(opts, so)) return rc;
     if (!rowptr || !col || !val || !items || !Yopp || !gram_tiles || !Xown || !workspace)
         return fail(ALS_ERR_INVALID_ARG, "als_half_sweep_cg_f32: null pointer");
     if (n_rows < 1 || n_rows > INT32_MAX || n_items < n_rows || n_long < 0 || n_slots < 0 || n_opp < 1)
@@ -1312,13 +1323,10 @@ int32_t als_half_sweep_wide_(const int64_t *rowptr, const int32_t *col, const fl
     // 16-byte loads: whole vectors inside a row, aligned base, 32-bit row offsets in vector units
     const bool vec = (f % 4 == 0) && (ldy % 4 == 0) && ((uintptr_t)Yopp % 16 == 0) && (n_opp * (ldy / 4) < 0xffffffffLL);
     hipStream_t st = (hipStream_t)stream;
-    hipEvent_t tap0 = g_tap_begin, tap1 = g_tap_end;
-    g_tap_begin = g_tap_end = nullptr;
-    if (tap0) ALS_HIP_CHECK(hipEventRecord(tap0, st));
+    if (so.tap0) ALS_HIP_CHECK(hipEventRecord(so.tap0, st));
     if (vec) hipLaunchKernelGGL(wide_row_items_kernel<true>, dim3((unsigned)n_items), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(wide_row_items_kernel<false>, dim3((unsigned)n_items), dim3(256), 0, st, p);
     ALS_HIP_CHECK(hipGetLastError());
-    if (tap1) ALS_HIP_CHECK(hipEventRecord(tap1, st));
     if (n_long > 0) {
         hipLaunchKernelGGL(sum_slots_kernel, dim3((unsigned)n_long, (unsigned)((WR_SLOT_FLOATS + 255) / 256)), dim3(256), 0,
                            st, p.partials, p.long_rows, WR_SLOT_FLOATS);
@@ -1326,6 +1334,7 @@ int32_t als_half_sweep_wide_(const int64_t *rowptr, const int32_t *col, const fl
         hipLaunchKernelGGL(wide_row_long_kernel, dim3((unsigned)n_long), dim3(256), 0, st, p);
         ALS_HIP_CHECK(hipGetLastError());
     }
+    if (so.tap1) ALS_HIP_CHECK(hipEventRecord(so.tap1, st));
     if (absdiff_out) return als_sum_rowdiff_(p.rowdiff, n_rows, diff_partials, absdiff_out, st);
     return ALS_OK;
 }

@@ -91,8 +91,10 @@ WORKLOADS = {
     "c2_ml25m_syn": dict(n_users=162541, n_items=59047, nnz=25000095, f=64, lamb=0.01, alpha=40.0, iters=15),
     # one GPU's eighth of the 10 M x 1 M, 1 B-entry matrix (f=128): 1.25 M users over all 1 M items.  Both
     # factor tables (0.5 GB and 0.64 GB) exceed the 256 MB Infinity Cache, so the gathers come from HBM.
+    # With several GPUs the blocks' entry counts differ by up to +-10 % (block_jitter) and the user shards are cut by
+    # stored entries (balance_users), not at the block boundaries: ranks own different numbers of rows.
     "c3_shard_syn": dict(n_users=1250000, n_items=1000000, nnz=125000000, f=128, lamb=0.01, alpha=40.0, iters=15,
-                         init="device"),
+                         init="device", block_jitter=0.1, balance_users=True),
     # one GPU's eighth of the 50 M x 5 M, 4 B-entry matrix (f=256, conjugate-gradient solver)
     "c4_shard_syn": dict(n_users=6250000, n_items=5000000, nnz=500000000, f=256, lamb=0.01, alpha=40.0, iters=15,
                          init="device", solver="cg"),

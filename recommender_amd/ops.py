@@ -38,6 +38,20 @@ def _need(t, dtype, name, dim=None):
         raise ValueError("%s must be %d-dimensional" % (name, dim))
 
 
+def _index(t, dtype, name):
+    """1-D index tensor the kernels read as a dense array: right dtype AND contiguous."""
+    _need(t, dtype, name, 1)
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous (a strided view would be read as a dense array)" % name)
+
+
+def _same_device(first, *others):
+    """Every tensor of one call must live on one device: the call is launched on that device's stream."""
+    for t in others:
+        if t is not None and t.device != first.device:
+            raise ValueError("tensors of one call live on different devices (%s, %s)" % (first.device, t.device))
+
+
 def _factor_ld(t, name):
     """Row-major [n, f] with unit inner stride; returns the leading dimension in elements."""
     _need(t, torch.float32, name, 2)
@@ -46,17 +60,30 @@ def _factor_ld(t, name):
     return t.stride(0)
 
 
-def set_accumulate_mode(mode):
-    """"bf16x3" (default): the per-row normal matrix is accumulated on the bf16 matrix cores from an
-    exact 3-way split of every float32 value; "fp32": float32 matrix-core fma chain.  Process-wide."""
-    codes = {"fp32": _lib.ACCUMULATE_FP32, "bf16x3": _lib.ACCUMULATE_BF16X3}
-    if mode not in codes:
-        raise ValueError("mode must be 'fp32' or 'bf16x3'")
-    check(lib.als_set_accumulate_mode(codes[mode]), "als_set_accumulate_mode")
+def sweep_opts(accumulate="default", row_kernel="auto", tap=None):
+    """Per-call options of the half-sweeps (als_sweep_opts_t), or None when every one is the default.
+    accumulate: "bf16x3" (= "default": the per-row normal matrix is accumulated on the bf16 matrix cores
+    from an exact 3-way split of every float32 value) or "fp32" (float32 matrix-core fma chain).
+    row_kernel: "auto", "wave" or "workgroup" - which per-row kernel handles 64 < f <= 128.
+    tap: (begin, end) torch.cuda.Event pair recorded around the call's per-row kernels."""
+    if accumulate not in _lib.ACCUMULATE_MODES:
+        raise ValueError("accumulate must be one of %s" % sorted(_lib.ACCUMULATE_MODES))
+    if row_kernel not in _lib.ROW_KERNELS:
+        raise ValueError("row_kernel must be one of %s" % sorted(_lib.ROW_KERNELS))
+    if accumulate == "default" and row_kernel == "auto" and tap is None:
+        return None
+    o = _lib.SweepOpts(_lib.ACCUMULATE_MODES[accumulate], _lib.ROW_KERNELS[row_kernel], None, None)
+    if tap is not None:
+        o.tap_begin, o.tap_end = tap[0].cuda_event, tap[1].cuda_event
+    return o
 
 
-def get_accumulate_mode():
-    return {_lib.ACCUMULATE_FP32: "fp32", _lib.ACCUMULATE_BF16X3: "bf16x3"}[lib.als_get_accumulate_mode()]
+def _opts_ref(opts):
+    if opts is None:
+        return None
+    if not isinstance(opts, _lib.SweepOpts):
+        raise ValueError("opts must come from ops.sweep_opts()")
+    return ctypes.byref(opts)
 
 
 # ----------------------------------------------------------------------------- plan (host only)
@@ -214,8 +241,10 @@ def gram(Y, lamb, out=None, n=None):
     need = lib.als_gram_workspace_bytes(n, f)
     if out._ws is None or out._ws.numel() < need:
         out._ws = torch.empty(need, dtype=torch.uint8, device=Y.device)
-    check(lib.als_gram_f32(_ptr(Y), n, f, ldy, float(lamb), _ptr(out.gram), _ptr(out.tiles), _ptr(out._ws),
-                           out._ws.numel(), _stream()), "als_gram_f32")
+    _same_device(Y, out.gram, out.tiles, out._ws)
+    with torch.cuda.device(Y.device):
+        check(lib.als_gram_f32(_ptr(Y), n, f, ldy, float(lamb), _ptr(out.gram), _ptr(out.tiles), _ptr(out._ws),
+                               out._ws.numel(), _stream()), "als_gram_f32")
     return out
 
 
@@ -235,8 +264,10 @@ def gram_partials(Y, row_begin, row_end, super_out=None, ws=None):
     need = lib.als_gram_workspace_bytes(row_end - row_begin, f)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=Y.device)
-    check(lib.als_gram_partials_f32(_ptr(Y), row_begin, row_end, f, ldy, _ptr(super_out), _ptr(ws), ws.numel(),
-                                    _stream()), "als_gram_partials_f32")
+    _same_device(Y, super_out, ws)
+    with torch.cuda.device(Y.device):
+        check(lib.als_gram_partials_f32(_ptr(Y), row_begin, row_end, f, ldy, _ptr(super_out), _ptr(ws), ws.numel(),
+                                        _stream()), "als_gram_partials_f32")
     return super_out
 
 
@@ -247,16 +278,18 @@ def gram_finalize(super_partials, f, lamb, out=None):
     if out is None:
         out = GramCache(f, lamb, super_partials.device)
     out.lamb = float(lamb)
-    check(lib.als_gram_finalize_f32(_ptr(super_partials), super_partials.shape[0], f, float(lamb), _ptr(out.gram),
-                                    _ptr(out.tiles), _stream()), "als_gram_finalize_f32")
+    _same_device(super_partials, out.gram, out.tiles)
+    with torch.cuda.device(super_partials.device):
+        check(lib.als_gram_finalize_f32(_ptr(super_partials), super_partials.shape[0], f, float(lamb), _ptr(out.gram),
+                                        _ptr(out.tiles), _stream()), "als_gram_finalize_f32")
     return out
 
 
 # ----------------------------------------------------------------------------- half sweep
-def half_sweep(csr, Yopp, gram_cache, Xown, alpha, absdiff=None, info=None):
+def half_sweep(csr, Yopp, gram_cache, Xown, alpha, absdiff=None, info=None, opts=None):
     """One half-sweep: every row of `csr` re-solves its row of Xown (in place) against the
     fixed factor Yopp.  Returns the device scalar sum|X_old - X_new| (float64, 1 element);
-    divide by n*k for run_als_epoch's return value (reclibwh/core/ALS.py:233)."""
+    divide by n*k for run_als_epoch's return value (reclibwh/core/ALS.py:233).  opts: sweep_opts(...)."""
     if not isinstance(csr, DeviceCSR):
         raise ValueError("csr must be a DeviceCSR")
     ldy = _factor_ld(Yopp, "Yopp")
@@ -280,12 +313,12 @@ def half_sweep(csr, Yopp, gram_cache, Xown, alpha, absdiff=None, info=None):
         check(lib.als_half_sweep_csr_f32(
             _ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.val), csr.shape[0], _ptr(csr.row_ids), _ptr(csr.items),
             csr.n_items, _ptr(csr.long_rows), csr.n_long, csr.n_slots, csr.chunk_nnz, _ptr(Yopp), csr.shape[1], ldy,
-            _ptr(gram_cache.tiles), f, float(alpha), _ptr(Xown), ldx, _ptr(absdiff), _ptr(info), _ptr(ws),
-            ws.numel(), _stream()), "als_half_sweep_csr_f32")
+            _ptr(gram_cache.tiles), f, float(alpha), _ptr(Xown), ldx, _ptr(absdiff), _ptr(info), _opts_ref(opts),
+            _ptr(ws), ws.numel(), _stream()), "als_half_sweep_csr_f32")
     return absdiff
 
 
-def half_sweep_cg(csr, Yopp, gram_cache, Xown, alpha, cg_steps, absdiff=None, info=None, form="auto"):
+def half_sweep_cg(csr, Yopp, gram_cache, Xown, alpha, cg_steps, absdiff=None, info=None, form="auto", opts=None):
     """One half-sweep by `cg_steps` conjugate-gradient steps per row, warm-started at the current
     rows of Xown (updated in place).  Same contract as half_sweep otherwise; 1 <= f <= 256.
     form: "matrix" - one gather pass, the steps run on the row's formed matrix in registers;
@@ -321,7 +354,7 @@ def half_sweep_cg(csr, Yopp, gram_cache, Xown, alpha, cg_steps, absdiff=None, in
             csr.n_items, _ptr(csr.long_rows), csr.n_long, csr.n_slots, csr.chunk_nnz, _ptr(Yopp), csr.shape[1], ldy,
             _ptr(gram_cache.gram), _ptr(gram_cache.tiles), float(gram_cache.lamb), f, float(alpha), cg_steps,
             _lib.CG_FORMS[form], _ptr(Xown), ldx, _ptr(absdiff),
-            _ptr(info), _ptr(ws), ws.numel(), _stream()), "als_half_sweep_cg_f32")
+            _ptr(info), _opts_ref(opts), _ptr(ws), ws.numel(), _stream()), "als_half_sweep_cg_f32")
     return absdiff
 
 
@@ -338,7 +371,7 @@ def scores(X, Y, user_ids=None, M=None, out=None):
     if not (1 <= M <= Y.shape[0]):
         raise ValueError("M out of range")
     if user_ids is not None:
-        _need(user_ids, torch.int64, "user_ids", 1)
+        _index(user_ids, torch.int64, "user_ids")
         nu = user_ids.shape[0]
         if nu and (int(user_ids.min()) < 0 or int(user_ids.max()) >= X.shape[0]):
             raise ValueError("user id out of range")
@@ -351,6 +384,7 @@ def scores(X, Y, user_ids=None, M=None, out=None):
     _need(out, torch.float32, "out", 2)
     if out.shape[0] < nu or out.shape[1] < M or out.stride(1) != 1:
         raise ValueError("out too small or not row-major")
+    _same_device(X, Y, user_ids, out)
     with torch.cuda.device(X.device):
         check(lib.als_scores_f32(_ptr(X), ldx, _ptr(user_ids), nu, _ptr(Y), ldy, M, f, _ptr(out), out.stride(0),
                                  _stream()), "als_scores_f32")
@@ -371,8 +405,8 @@ def topk_rows(score_rows, k, exclude=None):
     ex_ptr = ex_col = None
     if exclude is not None:
         ex_ptr, ex_col = exclude
-        _need(ex_ptr, torch.int64, "exclude rowptr", 1)
-        _need(ex_col, torch.int32, "exclude col", 1)
+        _index(ex_ptr, torch.int64, "exclude rowptr")
+        _index(ex_col, torch.int32, "exclude col")
         if ex_ptr.shape[0] != n + 1:
             raise ValueError("exclude rowptr must have n_rows + 1 entries")
     idx = torch.empty((n, k), dtype=torch.int32, device=score_rows.device)
@@ -387,7 +421,7 @@ def predict_pairs(X, Y, u, i):
     """out[p] = <X[u[p]], Y[i[p]]>: the ALS model's output for explicit (user, item) pairs
     (reclibwh/core/ALS.py:359-362)."""
     ldx = _factor_ld(X, "X"); ldy = _factor_ld(Y, "Y")
-    _need(u, torch.int64, "u", 1); _need(i, torch.int64, "i", 1)
+    _index(u, torch.int64, "u"); _index(i, torch.int64, "i")
     if u.shape != i.shape or u.numel() < 1:
         raise ValueError("u and i must be equally long, non-empty")
     if int(u.min()) < 0 or int(u.max()) >= X.shape[0] or int(i.min()) < 0 or int(i.max()) >= Y.shape[0]:
@@ -435,7 +469,7 @@ def recommend_topk(X, Y, users, k, M=None, exclude_csr=None, block_users=4096, f
     f = X.shape[1]
     if Y.shape[1] != f or not (1 <= M <= Y.shape[0]):
         raise ValueError("factor counts differ or M out of range")
-    _need(users, torch.int64, "users", 1)
+    _index(users, torch.int64, "users")
     nu = users.shape[0]
     k = int(k)
     if not (1 <= k <= min(1024, M)):

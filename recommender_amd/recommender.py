@@ -58,6 +58,7 @@ class RecommenderALS:
         self.X = self.Y = None
         self.Utrain = self.Utest = None
         self.engine = None
+        self._foldin_cache = None
         self.start_epoch = 0
         self.trace, self.eval_epochs, self.eval_scores = [], [], []
         if mode == "predict":
@@ -136,6 +137,10 @@ class RecommenderALS:
             raise FloatingPointError("%d row systems were not positive definite in float32" % bad)
         return self.trace
 
+    def fit(self, **kwargs):
+        """Algorithm.fit (reclibwh/core/Environment.py:26-30; ALSTrainer.fit, ALS.py:320-357): train()."""
+        return self.train(**kwargs)
+
     # ------------------------------------------------------------------ persistence
     def save(self, path=None):
         path = self.model_path if path is None else path
@@ -181,6 +186,7 @@ class RecommenderALS:
                 if k in cfg: self.config[k] = cfg[k]
             self.start_epoch = int(cfg.get("start_epoch", 0))
         self.engine = None
+        self._foldin_cache = None
         return self
 
     # ------------------------------------------------------------------ inference
@@ -198,6 +204,10 @@ class RecommenderALS:
         (RecommenderService.py:16-29)."""
         k = min(int(k), self.n_items)
         ex = (self.Utrain.indptr.astype(np.int64), self.Utrain.indices) if (filter_rated and self.Utrain is not None) else None
+        if ex is not None:
+            u = np.asarray(users, dtype=np.int64).reshape(-1)
+            if u.size and (u.min() < 0 or u.max() >= self.Utrain.shape[0]):
+                raise ValueError("filter_rated: user id outside the training matrix (%d users)" % self.Utrain.shape[0])
         idx, val = ops.recommend_topk(self.X, self.Y, self._idx(users), k, M=self.n_items, exclude_csr=ex)
         return idx.cpu().numpy().astype(np.int64), val.cpu().numpy()
 
@@ -210,16 +220,24 @@ class RecommenderALS:
         idx, val = ops.recommend_topk(Yn, Yn, self._idx(items), k, M=self.n_items)
         return idx.cpu().numpy().astype(np.int64), val.cpu().numpy()
 
-    def update_user(self, rows, cols, vals):
-        """Fold-in (ALSUpdateAlgo.make_update_data + update_user, ALS.py:375-395): re-solves the
-        factor rows of the users in `rows` from the given (row, col, val) triplets alone, against
-        the current item factors.  Unlike the reference the item Gram is refreshed first
-        (the reference reuses the cache of the last training epoch)."""
+    def similar(self, item, k=200):
+        """SimAlgo.similar (Environment.py:20-24; SimpleMFSimAlgo.similar, RecAlgos.py:61-73) for a 1-D array of
+        item ids: (ranked ids, cosine similarities), best first, cut to the first k columns."""
+        item = np.asarray(item)
+        if item.ndim != 1:
+            raise ValueError("item must be a 1-D array of item ids")                    # RecAlgos.py:66
+        return self.similar_to(item, k)
+
+    def make_update_data(self, data):
+        """UpdateAlgo.make_update_data (Environment.py:43-45; ALS.py:387-395): turns (rows, cols, vals)
+        triplets into what update_user consumes - here a device CSR over the unique rows, each mapped to its
+        factor row, instead of the reference's padded-batch iterator.  No triplets: an empty list, as there."""
         import scipy.sparse as sps
+        rows, cols, vals = data
         rows = np.asarray(rows, dtype=np.int64); cols = np.asarray(cols, dtype=np.int64)
         vals = np.asarray(vals, dtype=np.float64)
         if len(rows) == 0:
-            return
+            return []                                                                   # ALS.py:390
         if not (len(rows) == len(cols) == len(vals)):
             raise ValueError("rows, cols and vals must have the same length")
         if rows.min() < 0 or cols.min() < 0 or rows.max() >= self.X.shape[0] or cols.max() >= self.n_items:
@@ -227,8 +245,30 @@ class RecommenderALS:
         uniq, inv = np.unique(rows, return_inverse=True)
         U = sps.csr_matrix((vals, (inv, cols)), shape=(len(uniq), self.n_items))   # duplicates sum, as csr_matrix does
         U.sort_indices()
-        csr = ops.DeviceCSR.from_scipy(U, self.device, self.config["chunk_nnz"], row_ids=uniq)
-        cache = ops.gram(self.Y, self.config["lamb"])
+        return ops.DeviceCSR.from_scipy(U, self.device, self.config["chunk_nnz"], row_ids=uniq)
+
+    def update_user(self, rows, cols=None, vals=None, refresh_gram=True):
+        """Fold-in (ALSUpdateAlgo.update_user, ALS.py:375-385): re-solves the factor rows of the given users from
+        their triplets alone, against the current item factors.  Call it with (rows, cols, vals) or with the
+        object make_update_data returned.
+
+        refresh_gram=True (default) computes the item Gram from the current Y first.  refresh_gram=False
+        reproduces the reference: the cached Gram is used as it stands (ALS.py:385 passes the cache 'Y2' and never
+        refreshes it) - after train() that is the Gram taken before the last item sweep (ALS.py:345-349), after a
+        load it is fresh (ALS.py:301-308), and later fold-ins keep using it."""
+        csr = rows if (cols is None and vals is None) else self.make_update_data((rows, cols, vals))
+        if isinstance(csr, list) and not csr:
+            return
+        if not isinstance(csr, ops.DeviceCSR) or csr.row_ids is None:
+            raise ValueError("update_user takes (rows, cols, vals) or the result of make_update_data")
+        if refresh_gram:
+            cache = ops.gram(self.Y, self.config["lamb"])
+        elif self.engine is not None and self.trace:
+            cache = self.engine.cache_Y                # as the last training epoch left it
+        else:                                          # nothing trained in this object: computed once, then reused
+            if self._foldin_cache is None:
+                self._foldin_cache = ops.gram(self.Y, self.config["lamb"])
+            cache = self._foldin_cache
         info = torch.zeros(1, dtype=torch.int32, device=self.device)
         f = self.X.shape[1]
         if self.config["solver"] == "cg" or f > 128:

@@ -53,7 +53,7 @@ def gram(Y, lamb, out=None, n=None):
     return gram_finalize(gram_partials(Y, 0, n), Y.shape[1], lamb, out)
 
 
-def half_sweep(csr, Yopp, cache, Xown, alpha, absdiff=None, info=None):
+def half_sweep(csr, Yopp, cache, Xown, alpha, absdiff=None, info=None, opts=None):
     old = Xown.numpy().astype(np.float64)
     new = c_oracle.half_sweep(csr.indptr, csr.indices, csr.data, Yopp.numpy().astype(np.float64), old, cache.lamb,
                               alpha, Y2=cache.gram.numpy())
@@ -64,7 +64,7 @@ def half_sweep(csr, Yopp, cache, Xown, alpha, absdiff=None, info=None):
     return absdiff
 
 
-def half_sweep_cg(csr, Yopp, cache, Xown, alpha, cg_steps, absdiff=None, info=None):
+def half_sweep_cg(csr, Yopp, cache, Xown, alpha, cg_steps, absdiff=None, info=None, form="auto", opts=None):
     from oracle import als_ref
     old = Xown.numpy().astype(np.float64)
     new = als_ref.half_sweep_cg(csr.indptr, csr.indices, csr.data, Yopp.numpy().astype(np.float64), old, cache.lamb,

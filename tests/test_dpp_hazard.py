@@ -38,5 +38,28 @@ def test_shipped_solve_kernels_keep_the_distance():
 def test_checker_flags_a_matrix_core_result_read_too_early():
     mfma = "\tv_mfma_f32_16x16x4_f32 v[4:7], v1, v2, v[4:7]\n"
     assert chk.check("_Zk:\n" + mfma + "\tv_add_f32_e32 v1, v2, v3\n" * 5 + DPP)
-    assert not chk.check("_Zk:\n" + mfma + "\tv_add_f32_e32 v1, v2, v3\n" * 18 + DPP)
-    assert not chk.check("_Zk:\n" + mfma + "\ts_nop 7\n\ts_nop 7\n\ts_nop 1\n" + DPP)
+    assert not chk.check("_Zk:\n" + mfma + "\tv_add_f32_e32 v1, v2, v3\n" * 12 + DPP)      # 8 passes + 4
+    assert not chk.check("_Zk:\n" + mfma + "\ts_nop 7\n\ts_nop 3\n" + DPP)
+    big = "\tv_mfma_f32_32x32x2_f32 v[0:15], v20, v21, v[0:15]\n"                               # 16 passes
+    assert chk.check("_Zk:\n" + big + "\tv_add_f32_e32 v30, v31, v32\n" * 12 + DPP)
+    assert not chk.check("_Zk:\n" + big + "\tv_add_f32_e32 v30, v31, v32\n" * 20 + DPP)
+
+
+def test_checker_reads_two_operand_dpp_instructions():
+    """`v_mov_b32_dpp v1, v2 quad_perm:[1,0,3,2] ...`: the register read through DPP is followed by modifiers, not
+    by a comma; the compiler's own DPP moves are of this form and must be checked like the others."""
+    mov = "\tv_mov_b32_dpp v1, v2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+    assert chk.check("_Zk:\n\tv_mov_b32_e32 v2, v7\n" + mov)
+    assert not chk.check("_Zk:\n\tv_mov_b32_e32 v2, v7\n\ts_nop 1\n" + mov)
+    assert not chk.check("_Zk:\n\tv_mov_b32_e32 v3, v7\n" + mov)
+
+
+def test_checker_is_conservative_at_labels():
+    """A DPP read right behind a label may follow a write on the other path into the label."""
+    assert chk.check("_Zk:\n\tv_mov_b32_e32 v1, v7\n\ts_nop 1\n.LBB0_3:\n" + DPP)
+    assert not chk.check("_Zk:\n.LBB0_3:\n\tv_add_f32_e32 v1, v2, v3\n\tv_add_f32_e32 v2, v2, v3\n" + DPP)
+
+
+def test_flags_come_from_the_makefile():
+    flags = chk.makefile_flags()
+    assert "-O3" in flags and "-fno-slp-vectorize" in flags

@@ -37,12 +37,12 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-def _sweep(ra, ptr, ind, dat, shape, Yfix, Xold, lamb, alpha, chunk_nnz=2048, row_ids=None):
+def _sweep(ra, ptr, ind, dat, shape, Yfix, Xold, lamb, alpha, chunk_nnz=2048, row_ids=None, opts=None):
     csr = ra.DeviceCSR(ptr, ind, dat, shape, "cuda", chunk_nnz=chunk_nnz, row_ids=row_ids)
     Y = _dev(Yfix); X = _dev(Xold)
     gc = ra.gram(Y, lamb)
     info = torch.zeros(1, dtype=torch.int32, device="cuda")
-    d = ra.half_sweep(csr, Y, gc, X, alpha, info=info)
+    d = ra.half_sweep(csr, Y, gc, X, alpha, info=info, opts=opts)
     torch.cuda.synchronize()
     assert int(info.item()) == 0
     return X.cpu().numpy().astype(np.float64), float(d.item())
@@ -213,18 +213,16 @@ def test_accumulate_modes_agree_and_both_hold_parity(ra, f):
     X0 = rng.normal(0, 1 / np.sqrt(f), size=(N, f)).astype(np.float32)
     ref = c_oracle.half_sweep(ptr, ind, dat, Y0, X0, 0.01, 40.0, dtype=np.float64, nthreads=8)
     out = {}
-    try:
-        for mode in ("fp32", "bf16x3"):
-            ra.ops.set_accumulate_mode(mode)
-            assert ra.ops.get_accumulate_mode() == mode
-            a, _ = _sweep(ra, ptr, ind, dat, (N, M), Y0, X0, 0.01, 40.0, chunk_nnz=128)
-            b, _ = _sweep(ra, ptr, ind, dat, (N, M), Y0, X0, 0.01, 40.0, chunk_nnz=128)
-            assert np.array_equal(a, b)
-            assert _rel(a, ref) < 1e-4, (mode, _rel(a, ref))
-            out[mode] = a
-    finally:
-        ra.ops.set_accumulate_mode("bf16x3")
+    for mode in ("fp32", "bf16x3"):       # a per-call option: nothing to restore afterwards
+        o = ra.ops.sweep_opts(accumulate=mode)
+        a, _ = _sweep(ra, ptr, ind, dat, (N, M), Y0, X0, 0.01, 40.0, chunk_nnz=128, opts=o)
+        b, _ = _sweep(ra, ptr, ind, dat, (N, M), Y0, X0, 0.01, 40.0, chunk_nnz=128, opts=o)
+        assert np.array_equal(a, b)
+        assert _rel(a, ref) < 1e-4, (mode, _rel(a, ref))
+        out[mode] = a
     assert _rel(out["bf16x3"], out["fp32"]) < 2e-5
+    dflt, _ = _sweep(ra, ptr, ind, dat, (N, M), Y0, X0, 0.01, 40.0, chunk_nnz=128)
+    assert np.array_equal(dflt, out["bf16x3"])          # no options = the documented default
 
 
 def test_integration_stub_from_the_docs_runs(ra):

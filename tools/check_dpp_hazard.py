@@ -19,23 +19,54 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "recommender_amd", "csrc")
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize"]          # the Makefile's CXXFLAGS that affect code generation
 SOURCES = ["als_kernels.hip", "als_cg.hip", "als_scoring.hip"]
 
-MFMA_STATES = 18
-_reg = re.compile(r"^v(\d+)$")
-_range = re.compile(r"^v\[(\d+):(\d+)\]$")
+
+def makefile_flags():
+    """The CXXFLAGS the library is built with: the environment's if set (make's `?=`), else the Makefile's own line,
+    so that a build with other flags or -D switches is checked as built."""
+    env = os.environ.get("CXXFLAGS")
+    if env is not None:
+        return env.split()
+    for line in open(os.path.join(CSRC, "Makefile")):
+        m = re.match(r"^CXXFLAGS\s*\?=\s*(.*)$", line)
+        if m:
+            return m.group(1).split()
+    raise RuntimeError("no CXXFLAGS line in %s" % os.path.join(CSRC, "Makefile"))
+
+
+MFMA_STATES = 20
+_operand = re.compile(r"^v(\d+)\b|^v\[(\d+):(\d+)\]")
+
+
+def _mfma_states(op):
+    """Wait states a vector read must keep after this matrix-core instruction wrote the register."""
+    passes = 16
+    if "16x16x4_f32" in op or "16x16x4f32" in op or "32x32x16" in op:
+        passes = 8
+    elif "16x16x32" in op or "16x16x16" in op:
+        passes = 4
+    elif "4x4x" in op:
+        passes = 2
+    return min(MFMA_STATES, passes + 4)
+
+
+class _Any:
+    """Stands for "any register may have been written" (a control-flow join: the code in front is not the only
+    predecessor)."""
+    def __and__(self, other):
+        return bool(other)
+    __rand__ = __and__
 
 
 def _written(operand):
-    """VGPR numbers named by a destination operand."""
-    m = _reg.match(operand)
-    if m:
+    """VGPR numbers named by an operand; modifiers after the register (`v2 quad_perm:[1`) are ignored."""
+    m = _operand.match(operand)
+    if not m:
+        return set()
+    if m.group(1) is not None:
         return {int(m.group(1))}
-    m = _range.match(operand)
-    if m:
-        return set(range(int(m.group(1)), int(m.group(2)) + 1))
-    return set()
+    return set(range(int(m.group(2)), int(m.group(3)) + 1))
 
 
 def check(text):
@@ -49,7 +80,12 @@ def check(text):
         if m:
             kernel, window = m.group(1), []
             continue
-        if not line or line.startswith(".") or line.endswith(":"):
+        if re.match(r"^\.?\w+:$", line):
+            # a label: branches arrive here from code this scan has not just seen (loop back-edges included), so
+            # anything may have been written zero wait states ago
+            window.append((0, _Any(), "label " + line, 2))
+            continue
+        if not line or line.startswith("."):
             continue
         parts = line.split(None, 1)
         op = parts[0]
@@ -68,9 +104,9 @@ def check(text):
         if op == "s_nop":
             window.append((int(args[0], 0) + 1, set(), line, 0))
         elif op.startswith("v_mfma") and args:
-            # a matrix-core result is not interlocked against a vector read either (up to 18 wait states for the
-            # longest instruction used here); the statements of the solve never follow one that closely
-            window.append((1, _written(args[0]), line, MFMA_STATES))
+            # a matrix-core result is not interlocked against a vector read either: passes + 4 wait states (the
+            # figure LLVM's hazard recognizer uses for gfx950, rounded up), passes = issue cycles / 4
+            window.append((1, _written(args[0]), line, _mfma_states(op)))
         elif op.startswith("v_") and args and not op.startswith("v_cmp") and not op.startswith("v_readlane") \
                 and not op.startswith("v_readfirstlane"):
             window.append((1, _written(args[0]), line, 2))
@@ -85,7 +121,8 @@ def assembly_of(src):
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "k.s")
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        subprocess.run([hipcc, "--offload-arch=gfx950", *FLAGS, "-I" + os.path.join(ROOT, "include"), "-S",
+        flags = [f for f in makefile_flags() if f not in ("-shared", "-Wall") and not f.startswith("-Wno-")]
+        subprocess.run([hipcc, "--offload-arch=gfx950", *flags, "-I" + os.path.join(ROOT, "include"), "-S",
                         "--cuda-device-only", "-o", out, src], check=True, cwd=CSRC, stderr=subprocess.DEVNULL)
         return open(out).read()
 
