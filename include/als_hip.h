@@ -180,6 +180,32 @@ int32_t als_half_sweep_csr_f32(const int64_t *rowptr, const int32_t *col, const 
                                void *workspace, size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Half-sweep for callers that cannot allocate device memory.  No counterpart in the reference: it is
+ * for code under HIP graph capture, tight serving loops (the fold-in of ALSUpdateAlgo.update_user is one)
+ * and harnesses that forbid hipMalloc.  Same computation, arguments and results (bit for bit) as
+ * als_half_sweep_csr_f32, but without the workspace: the scratch memory lives in a buffer of
+ * ALS_STATIC_SCRATCH_BYTES built into the library's code object, one copy per GPU, held until the process
+ * ends.  The call allocates and frees nothing.  It returns ALS_ERR_WORKSPACE, with the sizes in the message,
+ * when als_half_sweep_workspace_bytes(n_rows, n_slots, f) exceeds ALS_STATIC_SCRATCH_BYTES (16 MiB: e.g.
+ * 65 536 rows with up to 400 chunk slots at f = 128, or 1 400 at f = 64).
+ * `stream` must belong to the device that is current on the calling thread.  All calls on one GPU share that
+ * GPU's buffer: calls that can overlap on one GPU (different streams, or different threads) race; calls on
+ * one stream are ordered and safe, and no call depends on what an earlier one left in the buffer.
+ * als_static_scratch_init() resolves the buffer's address on the current device ahead of time (otherwise
+ * the first call on a device does it); als_static_scratch_bytes() returns the limit.
+ * ------------------------------------------------------------------------------------ */
+#define ALS_STATIC_SCRATCH_BYTES (16u << 20)
+size_t als_static_scratch_bytes(void);
+int32_t als_static_scratch_init(void);
+int32_t als_half_sweep_csr_static_f32(const int64_t *rowptr, const int32_t *col, const float *val, int64_t n_rows,
+                                      const int64_t *row_ids, const als_item_t *items, int64_t n_items,
+                                      const als_long_row_t *long_rows, int64_t n_long, int64_t n_slots,
+                                      int32_t chunk_nnz, const float *Yopp, int64_t n_opp, int64_t ldy,
+                                      const float *gram_tiles, int32_t f, float alpha, float *Xown, int64_t ldx,
+                                      double *absdiff_out, int32_t *info_out, const als_sweep_opts_t *opts,
+                                      void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Conjugate-gradient half-sweep, 1 <= f <= ALS_MAX_FACTORS.  Same normal equations and same
  * in-place update of Xown as als_half_sweep_csr_f32, but each row's system is advanced by
  * exactly `cg_steps` conjugate-gradient steps from the row's current value instead of being

@@ -51,6 +51,10 @@ SIGNATURES = {
     "als_half_sweep_cg_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32,
                                       c_vp, c_i64, c_i64, c_vp, c_vp, c_f32, c_i32, c_f32, c_i32, c_i32, c_vp, c_i64, c_vp,
                                       c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "als_static_scratch_bytes": (c_sz, []),
+    "als_static_scratch_init": (c_i32, []),
+    "als_half_sweep_csr_static_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32,
+                                              c_vp, c_i64, c_i64, c_vp, c_i32, c_f32, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "als_half_sweep_csr_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32,
                                        c_vp, c_i64, c_i64, c_vp, c_i32, c_f32, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz,
                                        c_vp]),

@@ -24,6 +24,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -45,6 +46,11 @@ int32_t als_gram_wide_partials_(const float *Y, int64_t row_begin, int64_t row_e
 int32_t als_gram_wide_finalize_(const float *super_in, int64_t n_super, int32_t f, float *gram_out, float *tiles_out,
                                 hipStream_t st);
 
+// Scratch of als_half_sweep_csr_static_f32, the entry point for callers that cannot allocate: chunk partials of
+// long rows, the per-row |delta| and its partial sums.  Every GPU the library runs on holds its own copy at its own
+// address; in host code the name is only a handle for hipGetSymbolAddress (static_scratch_ptr below), never an address.
+static __device__ __align__(256) unsigned char scratch[ALS_STATIC_SCRATCH_BYTES];
+
 namespace {
 
 // ----------------------------------------------------------------------------- errors
@@ -63,6 +69,25 @@ int fail(int code, const char *fmt, ...) {
         hipError_t e_ = (expr);                                                               \
         if (e_ != hipSuccess) return fail(ALS_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
+
+// Device address of `scratch` on the current device, resolved once per device (hipGetSymbolAddress) and kept.
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+void *g_scratch_ptr[MAX_DEVICES] = {};
+int32_t static_scratch_ptr(void **out) {
+    int dev = -1;
+    ALS_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEVICES) return fail(ALS_ERR_UNSUPPORTED, "device ordinal %d outside [0, %d)", dev, MAX_DEVICES);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        ALS_HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(ALS_ERR_HIP, "hipGetSymbolAddress returned a null address for the scratch buffer");
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return ALS_OK;
+}
 
 // ----------------------------------------------------------------------------- geometry
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1222,6 +1247,36 @@ int32_t als_half_sweep_csr_f32(const int64_t *rowptr, const int32_t *col, const 
     return als_half_sweep_tiles_(rowptr, col, val, n_rows, row_ids, items, n_items, long_rows, n_long, n_slots, chunk_nnz,
                                  Yopp, n_opp, ldy, gram_tiles, f, alpha, 0, Xown, ldx, absdiff_out, info_out, opts,
                                  workspace, ws_bytes, stream);
+}
+
+// ----------------------------------------------------------------------------- half sweep without a workspace argument
+size_t als_static_scratch_bytes(void) { return ALS_STATIC_SCRATCH_BYTES; }
+
+int32_t als_static_scratch_init(void) {
+    void *p;
+    return static_scratch_ptr(&p);
+}
+
+int32_t als_half_sweep_csr_static_f32(const int64_t *rowptr, const int32_t *col, const float *val, int64_t n_rows,
+                                      const int64_t *row_ids, const als_item_t *items, int64_t n_items,
+                                      const als_long_row_t *long_rows, int64_t n_long, int64_t n_slots, int32_t chunk_nnz,
+                                      const float *Yopp, int64_t n_opp, int64_t ldy, const float *gram_tiles, int32_t f,
+                                      float alpha, float *Xown, int64_t ldx, double *absdiff_out, int32_t *info_out,
+                                      const als_sweep_opts_t *opts, void *stream) {
+    const size_t need = als_half_sweep_workspace_bytes(n_rows, n_slots, f);
+    if (need == 0) return fail(ALS_ERR_UNSUPPORTED, "als_half_sweep_csr_static_f32: f=%d outside [1, %d] or negative sizes", f,
+                               ALS_MAX_FACTORS_EXACT);
+    if (need > ALS_STATIC_SCRATCH_BYTES)
+        return fail(ALS_ERR_WORKSPACE, "als_half_sweep_csr_static_f32: n_rows=%lld, n_slots=%lld at f=%d need %zu bytes of scratch, "
+                    "the built-in buffer holds %zu; use als_half_sweep_csr_f32 with a workspace", (long long)n_rows,
+                    (long long)n_slots, f, need, (size_t)ALS_STATIC_SCRATCH_BYTES);
+    void *ws;
+    if (const int32_t rc = static_scratch_ptr(&ws)) return rc;
+    // Nothing in the scratch has to start at zero: every partial slot, every row's |delta| and every partial sum is
+    // written by this call before this call reads it, so the previous call's contents are never seen.
+    return als_half_sweep_tiles_(rowptr, col, val, n_rows, row_ids, items, n_items, long_rows, n_long, n_slots, chunk_nnz,
+                                 Yopp, n_opp, ldy, gram_tiles, f, alpha, 0, Xown, ldx, absdiff_out, info_out, opts, ws,
+                                 ALS_STATIC_SCRATCH_BYTES, stream);
 }
 
 }  // extern "C"

@@ -286,10 +286,12 @@ def gram_finalize(super_partials, f, lamb, out=None):
 
 
 # ----------------------------------------------------------------------------- half sweep
-def half_sweep(csr, Yopp, gram_cache, Xown, alpha, absdiff=None, info=None, opts=None):
+def half_sweep(csr, Yopp, gram_cache, Xown, alpha, absdiff=None, info=None, opts=None, static_scratch=False):
     """One half-sweep: every row of `csr` re-solves its row of Xown (in place) against the
     fixed factor Yopp.  Returns the device scalar sum|X_old - X_new| (float64, 1 element);
-    divide by n*k for run_als_epoch's return value (reclibwh/core/ALS.py:233).  opts: sweep_opts(...)."""
+    divide by n*k for run_als_epoch's return value (reclibwh/core/ALS.py:233).  opts: sweep_opts(...).
+    static_scratch=True: als_half_sweep_csr_static_f32 - no workspace is allocated or passed, the library's built-in
+    per-GPU scratch buffer is used (small inputs only; absdiff must then be given to keep the call allocation free)."""
     if not isinstance(csr, DeviceCSR):
         raise ValueError("csr must be a DeviceCSR")
     ldy = _factor_ld(Yopp, "Yopp")
@@ -308,6 +310,14 @@ def half_sweep(csr, Yopp, gram_cache, Xown, alpha, absdiff=None, info=None, opts
         raise ValueError("Xown and Yopp must not alias")
     if absdiff is None:
         absdiff = torch.zeros(1, dtype=torch.float64, device=csr.device)
+    if static_scratch:
+        with torch.cuda.device(csr.device):
+            check(lib.als_half_sweep_csr_static_f32(
+                _ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.val), csr.shape[0], _ptr(csr.row_ids), _ptr(csr.items),
+                csr.n_items, _ptr(csr.long_rows), csr.n_long, csr.n_slots, csr.chunk_nnz, _ptr(Yopp), csr.shape[1], ldy,
+                _ptr(gram_cache.tiles), f, float(alpha), _ptr(Xown), ldx, _ptr(absdiff), _ptr(info), _opts_ref(opts),
+                _stream()), "als_half_sweep_csr_static_f32")
+        return absdiff
     ws = csr.workspace(f)
     with torch.cuda.device(csr.device):
         check(lib.als_half_sweep_csr_f32(
