@@ -969,6 +969,8 @@ __global__ __launch_bounds__(256) void sum_to_double_kernel(const T *__restrict_
 }
 
 #include "als_wide_row.inc"
+#include "als_row_wg.inc"
+#include "als_row_pipe.inc"
 
 // ----------------------------------------------------------------------------- host helpers
 inline int vw_for(int f) { return f <= 16 ? 1 : f <= 32 ? 2 : f <= 64 ? 4 : 8; }
@@ -1040,7 +1042,39 @@ template <int VW>
 static int32_t half_sweep_impl(const SweepParams &p, int64_t n_rows, int64_t n_items, int64_t n_long,
                                double *absdiff_out, double *diff_partials, bool vec, const SweepOpts &o, hipStream_t st) {
     if (o.tap0) ALS_HIP_CHECK(hipEventRecord(o.tap0, st));
-    if (n_items > 0) {
+    // 64 < f <= 128: the row's tiles over the 4 waves of a workgroup (als_row_wg.inc) where that kernel exists:
+    // 16-byte aligned rows, bf16 x 3 accumulate, conjugate-gradient steps
+    bool wg = false;
+    if constexpr (VW == 8) {
+        const bool can = vec && o.split;
+        if (o.row_kernel == ALS_ROW_KERNEL_WORKGROUP && !can)
+            return fail(ALS_ERR_UNSUPPORTED, "row_kernel WORKGROUP needs 64 < f <= 128 with 16-byte aligned factor rows and the "
+                        "bf16x3 accumulate");
+        wg = can && o.row_kernel == ALS_ROW_KERNEL_WORKGROUP;      // AUTO: the one-wave kernel until this one is faster
+    } else if (o.row_kernel == ALS_ROW_KERNEL_WORKGROUP) {
+        return fail(ALS_ERR_UNSUPPORTED, "row_kernel WORKGROUP exists for 64 < f <= 128 only (f=%d)", p.f);
+    }
+    if (n_items > 0 && wg) {
+        if constexpr (VW == 8) {
+            // the plan lists the chunk items of long rows first (one per partial slot), then the whole rows
+            const int64_t n_chunk_items = n_items - (n_rows - n_long), n_whole = n_rows - n_long;
+            if (n_chunk_items > 0) {
+                const dim3 grid((unsigned)n_chunk_items), block(256);
+                if (p.f == 128) hipLaunchKernelGGL(sweep_wg_kernel<true>, grid, block, 0, st, p);
+                else hipLaunchKernelGGL(sweep_wg_kernel<false>, grid, block, 0, st, p);
+                ALS_HIP_CHECK(hipGetLastError());
+            }
+            if (n_whole > 0) {
+                int dev = 0, cus = 0;
+                ALS_HIP_CHECK(hipGetDevice(&dev));
+                ALS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+                const dim3 grid((unsigned)std::min<int64_t>(n_whole, std::max(cus, 1))), block(64 * (4 + PIPE_SOLVERS));
+                if (p.f == 128) hipLaunchKernelGGL(sweep_pipe_kernel<true>, grid, block, 0, st, p, n_chunk_items, n_whole);
+                else hipLaunchKernelGGL(sweep_pipe_kernel<false>, grid, block, 0, st, p, n_chunk_items, n_whole);
+                ALS_HIP_CHECK(hipGetLastError());
+            }
+        }
+    } else if (n_items > 0) {
         const dim3 grid((unsigned)n_items), block(64);
         constexpr bool CAN_SPLIT = VW >= 4;
         const bool split = CAN_SPLIT && o.split;
