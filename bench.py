@@ -48,8 +48,8 @@ def parse():
                          "auto = matrix for f <= 128, lock_step above")
     ap.add_argument("--accumulate", default="bf16x3", choices=["bf16x3", "fp32"],
                     help="exact solver: how the per-row normal matrix is accumulated (see include/als_hip.h)")
-    ap.add_argument("--row-kernel", default="auto", choices=["auto", "wave", "workgroup"],
-                    help="64 < f <= 128: one wavefront per row, or the row's tiles over a 4-wave workgroup")
+    ap.add_argument("--row-kernel", default="auto", choices=["auto", "wave", "stream"],
+                    help="64 < f <= 128: one wavefront per row, or one resident wavefront per SIMD streaming its rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="only the headline measurement")
     ap.add_argument("--also-steps", type=int, default=3)

@@ -62,8 +62,11 @@ int32_t als_abi_version(void);
  *   row_kernel  which per-row kernel handles 64 < f <= 128 (results agree to float32 rounding, each
  *       is reproducible bit for bit):
  *       ALS_ROW_KERNEL_WAVE       one wavefront owns a row's whole matrix (144 accumulator registers);
- *       ALS_ROW_KERNEL_WORKGROUP  the row's 36 tiles are spread over the 4 wavefronts of a workgroup,
- *                                 operands shared through LDS (bf16 x 3 accumulate only);
+ *       ALS_ROW_KERNEL_STREAM     one resident wavefront per SIMD walks its share of the rows as one stream of
+ *                                 32-entry blocks: factor rows come by LDS-DMA several blocks ahead, across row
+ *                                 boundaries, and a block's matrix products overlap the next block's operand
+ *                                 split (bf16 x 3 accumulate, 16-byte aligned factor rows; long rows' chunk
+ *                                 items still run on the WAVE kernel);
  *       ALS_ROW_KERNEL_AUTO       the library's choice.
  *   tap_begin / tap_end  two hipEvent_t handles, or both NULL: recorded on `stream` immediately before
  *       the first and after the last per-row kernel of the call (benchmarks time the kernels with
@@ -73,7 +76,7 @@ int32_t als_abi_version(void);
 #define ALS_ACCUMULATE_FP32 2
 #define ALS_ROW_KERNEL_AUTO 0
 #define ALS_ROW_KERNEL_WAVE 1
-#define ALS_ROW_KERNEL_WORKGROUP 2
+#define ALS_ROW_KERNEL_STREAM 2
 typedef struct {
     int32_t accumulate;
     int32_t row_kernel;

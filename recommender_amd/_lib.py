@@ -23,7 +23,7 @@ MAX_FACTORS = 256
 MAX_FACTORS_EXACT = 128
 GRAM_WIDE_CHUNK_ROWS = 4096
 ACCUMULATE_MODES = {"default": 0, "bf16x3": 1, "fp32": 2}
-ROW_KERNELS = {"auto": 0, "wave": 1, "workgroup": 2}
+ROW_KERNELS = {"auto": 0, "wave": 1, "stream": 2}
 CG_FORMS = {"auto": 0, "lock_step": 1, "matrix": 2}
 
 c_i32, c_i64, c_f32, c_sz, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p

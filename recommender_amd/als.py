@@ -92,35 +92,70 @@ def run_als_epoch(csr, X, Y, cache, alpha, absdiff=None, info=None, backend=ops,
 
 def _host_staged(T, group):
     """RCCL ("nccl") moves device tensors directly and in stream order.  Any other backend (gloo in
-    tests and one-GPU rehearsals) gets host tensors: its own device-tensor path hung intermittently
-    with two ranks sharing one MI355X."""
+    tests and one-GPU rehearsals) gets host tensors.  ALS_COLLECTIVES_DEVICE=1 hands device tensors to
+    every backend (diagnosis of gloo's device path only)."""
+    import os
+    if os.environ.get("ALS_COLLECTIVES_DEVICE") == "1":
+        return False
     return T.is_cuda and torch.distributed.get_backend(group) != "nccl"
+
+
+_PADDED_RECV = {}      # (device, dtype, world, cap, trailing shape) -> receive buffer of the padded fallback, allocated once
+_UNEVEN_LIST_OK = [True]   # False once the backend has refused an all_gather with outputs of different sizes
 
 
 def _all_gather_row_blocks(T, starts, sizes, rank, group):
     """All-gather of one row block per rank of the replicated T, in place: rank r owns
-    T[starts[r] : starts[r] + sizes[r]] and every rank ends up with all of them.  One collective
-    whatever the sizes: unequal blocks travel padded to the longest."""
+    T[starts[r] : starts[r] + sizes[r]] and every rank ends up with all of them.  No padded staging:
+
+      * RCCL, equal blocks that tile T: all_gather_into_tensor straight into T;
+      * RCCL otherwise: all_gather into the list of T's own row-block views.  For blocks of different sizes torch
+        issues one broadcast per rank inside one RCCL group (every receive lands in place, nothing is staged or
+        padded).  Should a backend refuse the uneven form, the blocks travel padded through ONE receive buffer that
+        is allocated once and kept;
+      * other backends (gloo in tests): one broadcast per rank of host copies - they get host tensors (_host_staged)."""
     world = len(sizes)
     if max(sizes) == 0:
         return
     mine = T[starts[rank]: starts[rank] + sizes[rank]]
     equal = len(set(sizes)) == 1
-    host = _host_staged(T, group)
-    if equal and not host:
-        if T.is_contiguous() and all(starts[r] == r * sizes[0] for r in range(world)) and sizes[0] * world == T.shape[0]:
-            torch.distributed.all_gather_into_tensor(T, mine, group=group)      # blocks tile T: no staging at all
-        else:
-            torch.distributed.all_gather([T[starts[r]: starts[r] + sizes[r]] for r in range(world)], mine, group=group)
+    if _host_staged(T, group) or not T.is_cuda:
+        host = T.is_cuda
+        for r in range(world):
+            if not sizes[r]:
+                continue
+            blk = T[starts[r]: starts[r] + sizes[r]]
+            if host:
+                buf = blk.cpu() if r == rank else torch.empty(blk.shape, dtype=T.dtype, device="cpu")
+            else:
+                buf = blk
+            torch.distributed.broadcast(buf, src=torch.distributed.get_global_rank(group, r), group=group)
+            if host and r != rank:
+                blk.copy_(buf)
         return
+    if equal and T.is_contiguous() and all(starts[r] == r * sizes[0] for r in range(world)) and sizes[0] * world == T.shape[0]:
+        torch.distributed.all_gather_into_tensor(T, mine, group=group)      # blocks tile T: no staging at all
+        return
+    views = [T[starts[r]: starts[r] + sizes[r]] for r in range(world)]
+    if equal or _UNEVEN_LIST_OK[0]:
+        try:
+            torch.distributed.all_gather(views, mine, group=group)
+            return
+        except (RuntimeError, ValueError):
+            if equal:
+                raise
+            _UNEVEN_LIST_OK[0] = False      # the same on every rank: the sizes are checked before anything is sent
     cap = max(sizes)
-    send = torch.zeros((cap,) + tuple(T.shape[1:]), dtype=T.dtype, device="cpu" if host else T.device)
+    key = (T.device, T.dtype, world, cap, tuple(T.shape[1:]))
+    recv = _PADDED_RECV.get(key)
+    if recv is None:
+        recv = _PADDED_RECV[key] = torch.empty((world, cap) + tuple(T.shape[1:]), dtype=T.dtype, device=T.device)
+    send = recv[rank]
     send[: sizes[rank]] = mine
-    recv = [torch.empty_like(send) for _ in range(world)]
-    torch.distributed.all_gather(recv, send, group=group)
+    torch.distributed.all_gather_into_tensor(recv.view((world * cap,) + tuple(T.shape[1:])), send, group=group)
     for r in range(world):
         if r != rank and sizes[r]:
-            T[starts[r]: starts[r] + sizes[r]] = recv[r][: sizes[r]]
+            views[r].copy_(recv[r, : sizes[r]])
 
 
 def _all_gather_rows(T, bounds, rank, group):

@@ -677,27 +677,41 @@ __device__ __forceinline__ bool tiles_cg(const f32x4 (&T)[Geo<VW>::NT], const fl
     return spd;
 }
 
-// (acc + gram_tiles) x = b for one row; writes x to xrow and returns sum |x_old - x_new| (all lanes).
-// cg_steps == 0: blocked Cholesky; > 0: that many CG steps from the row's current value.
-template <int VW>
-__device__ __forceinline__ float solve_row_blocked(f32x4 (&acc)[Geo<VW>::NT], float (&bacc)[VW],
-                                                   const float *__restrict__ gtiles, const int f,
-                                                   float *__restrict__ xrow, int32_t *info, const int cg_steps,
-                                                   const int lane) {
+// tiles [T0, T1) of the tile-order Gram (a lane's 16 bytes of tile t at gtiles[(t * 64 + lane) * 4]) into g
+template <int T0, int T1>
+__device__ __forceinline__ void load_gram_tiles(f32x4 (&g)[T1 - T0], const float *__restrict__ gtiles, const int lane) {
 #pragma unroll
-    for (int t = 0; t < Geo<VW>::NT; ++t) {
-        acc[t] += f32x4{gtiles[(t * 4 + 0) * 64 + lane], gtiles[(t * 4 + 1) * 64 + lane], gtiles[(t * 4 + 2) * 64 + lane],
-                        gtiles[(t * 4 + 3) * 64 + lane]};           // two v_pk_add_f32
-        // keep the scheduler from hoisting all NT*4 loads to the top (they would need as many registers)
-        if (t % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+    for (int t = T0; t < T1; ++t) g[t - T0] = reinterpret_cast<const f32x4 *>(gtiles)[t * 64 + lane];
+}
+// acc += gram_tiles, GB tiles per batch of loads (all NT at once would need as many registers as acc)
+template <int VW, int GB>
+__device__ __forceinline__ void add_gram(f32x4 (&acc)[Geo<VW>::NT], const float *__restrict__ gtiles, const int lane) {
+    constexpr int NT = Geo<VW>::NT;
+#pragma unroll
+    for (int t0 = 0; t0 < NT; t0 += GB) {
+#pragma unroll
+        for (int t = t0; t < (t0 + GB < NT ? t0 + GB : NT); ++t)
+            acc[t] += reinterpret_cast<const f32x4 *>(gtiles)[t * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);      // keeps the scheduler from hoisting every load to the top
     }
+}
+template <int VW>
+__device__ __forceinline__ void load_row_values(float (&xold)[VW], const float *__restrict__ xrow, const int f, const int lane) {
     const int j = lane & 15;
-    float x[VW], xold[VW];
 #pragma unroll
     for (int t = 0; t < VW; ++t) {
         const int idx = fidx<VW>(j, t);
         xold[t] = idx < f ? xrow[idx] : 0.f;
     }
+}
+// T x = b for one row whose matrix T = acc + Gram is complete; xold: the row's current value.  Writes x to xrow
+// and returns sum |x_old - x_new| (all lanes).  cg_steps == 0: blocked Cholesky; > 0: that many CG steps from xold.
+template <int VW>
+__device__ __forceinline__ float solve_row_formed(f32x4 (&acc)[Geo<VW>::NT], float (&bacc)[VW], const float (&xold)[VW],
+                                                  const int f, float *__restrict__ xrow, int32_t *info,
+                                                  const int cg_steps, const int lane) {
+    const int j = lane & 15;
+    float x[VW];
     bool ok;
     if (cg_steps > 0) {
         // b = 0: the row holds nothing but stored zeros, which are dropped (ALS.py:79) - its solution is 0, and
@@ -727,6 +741,17 @@ __device__ __forceinline__ float solve_row_blocked(f32x4 (&acc)[Geo<VW>::NT], fl
     for (int o = 32; o >= 1; o >>= 1) d += __shfl_xor(d, o);
     if (!ok && lane == 0 && info) atomicAdd(info, 1);
     return d;
+}
+// (acc + gram_tiles) x = b for one row; writes x to xrow and returns sum |x_old - x_new| (all lanes).
+template <int VW>
+__device__ __forceinline__ float solve_row_blocked(f32x4 (&acc)[Geo<VW>::NT], float (&bacc)[VW],
+                                                   const float *__restrict__ gtiles, const int f,
+                                                   float *__restrict__ xrow, int32_t *info, const int cg_steps,
+                                                   const int lane) {
+    add_gram<VW, 4>(acc, gtiles, lane);
+    float xold[VW];
+    load_row_values<VW>(xold, xrow, f, lane);
+    return solve_row_formed<VW>(acc, bacc, xold, f, xrow, info, cg_steps, lane);
 }
 
 // ----------------------------------------------------------------------------- kernels
@@ -934,7 +959,8 @@ __global__ void gram_finalize_kernel(const float *__restrict__ super, const int6
             }
     const int i = (lane >> 4) * 4 + r, j = lane & 15;
     const int ai = fidx<VW>(i, ta), bi = fidx<VW>(j, tb);
-    tiles_out[e] = (ai == bi) ? (ai < f ? v + lamb : 1.0f) : v;   // padded indices: identity rows
+    // the tile-order copy holds a lane's 4 values of a tile side by side: one 16-byte load per tile in the sweeps
+    tiles_out[(t * 64 + lane) * 4 + r] = (ai == bi) ? (ai < f ? v + lamb : 1.0f) : v;   // padded indices: identity rows
     if (ai < f && bi < f && (ta != tb || i >= j)) {
         gram_out[ai * f + bi] = v;
         gram_out[bi * f + ai] = v;
@@ -969,8 +995,7 @@ __global__ __launch_bounds__(256) void sum_to_double_kernel(const T *__restrict_
 }
 
 #include "als_wide_row.inc"
-#include "als_row_wg.inc"
-#include "als_row_pipe.inc"
+#include "als_row_stream.inc"
 
 // ----------------------------------------------------------------------------- host helpers
 inline int vw_for(int f) { return f <= 16 ? 1 : f <= 32 ? 2 : f <= 64 ? 4 : 8; }
@@ -1027,7 +1052,7 @@ inline int32_t read_opts(const als_sweep_opts_t *o, SweepOpts &out) {
     if (o->accumulate != ALS_ACCUMULATE_DEFAULT && o->accumulate != ALS_ACCUMULATE_FP32 &&
         o->accumulate != ALS_ACCUMULATE_BF16X3)
         return fail(ALS_ERR_INVALID_ARG, "als_sweep_opts_t: unknown accumulate mode %d", o->accumulate);
-    if (o->row_kernel != ALS_ROW_KERNEL_AUTO && o->row_kernel != ALS_ROW_KERNEL_WAVE && o->row_kernel != ALS_ROW_KERNEL_WORKGROUP)
+    if (o->row_kernel != ALS_ROW_KERNEL_AUTO && o->row_kernel != ALS_ROW_KERNEL_WAVE && o->row_kernel != ALS_ROW_KERNEL_STREAM)
         return fail(ALS_ERR_INVALID_ARG, "als_sweep_opts_t: unknown row_kernel %d", o->row_kernel);
     if ((o->tap_begin == nullptr) != (o->tap_end == nullptr))
         return fail(ALS_ERR_INVALID_ARG, "als_sweep_opts_t: pass both tap events or neither");
@@ -1042,35 +1067,44 @@ template <int VW>
 static int32_t half_sweep_impl(const SweepParams &p, int64_t n_rows, int64_t n_items, int64_t n_long,
                                double *absdiff_out, double *diff_partials, bool vec, const SweepOpts &o, hipStream_t st) {
     if (o.tap0) ALS_HIP_CHECK(hipEventRecord(o.tap0, st));
-    // 64 < f <= 128: the row's tiles over the 4 waves of a workgroup (als_row_wg.inc) where that kernel exists:
-    // 16-byte aligned rows, bf16 x 3 accumulate, conjugate-gradient steps
-    bool wg = false;
+    // 64 < f <= 128 with 16-byte aligned rows and the bf16 x 3 accumulate: the whole rows can go to the persistent
+    // stream kernel (als_row_stream.inc)
+    int rk = ALS_ROW_KERNEL_WAVE;
     if constexpr (VW == 8) {
         const bool can = vec && o.split;
-        if (o.row_kernel == ALS_ROW_KERNEL_WORKGROUP && !can)
-            return fail(ALS_ERR_UNSUPPORTED, "row_kernel WORKGROUP needs 64 < f <= 128 with 16-byte aligned factor rows and the "
+        if (o.row_kernel == ALS_ROW_KERNEL_STREAM && !can)
+            return fail(ALS_ERR_UNSUPPORTED, "row_kernel STREAM needs 64 < f <= 128 with 16-byte aligned factor rows and the "
                         "bf16x3 accumulate");
-        wg = can && o.row_kernel == ALS_ROW_KERNEL_WORKGROUP;      // AUTO: the one-wave kernel until this one is faster
-    } else if (o.row_kernel == ALS_ROW_KERNEL_WORKGROUP) {
-        return fail(ALS_ERR_UNSUPPORTED, "row_kernel WORKGROUP exists for 64 < f <= 128 only (f=%d)", p.f);
+        if (can && o.row_kernel != ALS_ROW_KERNEL_AUTO) rk = o.row_kernel;
+        // AUTO: the stream kernel once every resident wave (4 per CU) has a whole row of its own; both kernels
+        // return the same bits, so the choice never shows in the results
+        if (can && o.row_kernel == ALS_ROW_KERNEL_AUTO) {
+            int dev = 0, cus = 0;
+            ALS_HIP_CHECK(hipGetDevice(&dev));
+            ALS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            if (n_rows - n_long >= 4 * (int64_t)std::max(cus, 1)) rk = ALS_ROW_KERNEL_STREAM;
+        }
+    } else if (o.row_kernel == ALS_ROW_KERNEL_STREAM) {
+        return fail(ALS_ERR_UNSUPPORTED, "row_kernel STREAM exists for 64 < f <= 128 only (f=%d)", p.f);
     }
-    if (n_items > 0 && wg) {
+    if (n_items > 0 && rk == ALS_ROW_KERNEL_STREAM) {
         if constexpr (VW == 8) {
             // the plan lists the chunk items of long rows first (one per partial slot), then the whole rows
             const int64_t n_chunk_items = n_items - (n_rows - n_long), n_whole = n_rows - n_long;
+            int dev = 0, cus = 0;
+            ALS_HIP_CHECK(hipGetDevice(&dev));
+            ALS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            cus = std::max(cus, 1);
             if (n_chunk_items > 0) {
-                const dim3 grid((unsigned)n_chunk_items), block(256);
-                if (p.f == 128) hipLaunchKernelGGL(sweep_wg_kernel<true>, grid, block, 0, st, p);
-                else hipLaunchKernelGGL(sweep_wg_kernel<false>, grid, block, 0, st, p);
+                const dim3 grid((unsigned)n_chunk_items), block(64);
+                if (p.f == 128) hipLaunchKernelGGL((sweep_items_kernel<VW, true, true, true>), grid, block, 0, st, p);
+                else hipLaunchKernelGGL((sweep_items_kernel<VW, true, false, true>), grid, block, 0, st, p);
                 ALS_HIP_CHECK(hipGetLastError());
             }
             if (n_whole > 0) {
-                int dev = 0, cus = 0;
-                ALS_HIP_CHECK(hipGetDevice(&dev));
-                ALS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-                const dim3 grid((unsigned)std::min<int64_t>(n_whole, std::max(cus, 1))), block(64 * (4 + PIPE_SOLVERS));
-                if (p.f == 128) hipLaunchKernelGGL(sweep_pipe_kernel<true>, grid, block, 0, st, p, n_chunk_items, n_whole);
-                else hipLaunchKernelGGL(sweep_pipe_kernel<false>, grid, block, 0, st, p, n_chunk_items, n_whole);
+                const dim3 grid((unsigned)std::min<int64_t>(n_whole, 4 * (int64_t)cus)), block(64);      // one wave per SIMD
+                if (p.f == 128) hipLaunchKernelGGL(sweep_stream_kernel<true>, grid, block, 0, st, p, n_chunk_items, n_whole);
+                else hipLaunchKernelGGL(sweep_stream_kernel<false>, grid, block, 0, st, p, n_chunk_items, n_whole);
                 ALS_HIP_CHECK(hipGetLastError());
             }
         }

@@ -64,7 +64,7 @@ def sweep_opts(accumulate="default", row_kernel="auto", tap=None):
     """Per-call options of the half-sweeps (als_sweep_opts_t), or None when every one is the default.
     accumulate: "bf16x3" (= "default": the per-row normal matrix is accumulated on the bf16 matrix cores
     from an exact 3-way split of every float32 value) or "fp32" (float32 matrix-core fma chain).
-    row_kernel: "auto", "wave" or "workgroup" - which per-row kernel handles 64 < f <= 128.
+    row_kernel: "auto", "wave" or "stream" - which per-row kernel handles 64 < f <= 128.
     tap: (begin, end) torch.cuda.Event pair recorded around the call's per-row kernels."""
     if accumulate not in _lib.ACCUMULATE_MODES:
         raise ValueError("accumulate must be one of %s" % sorted(_lib.ACCUMULATE_MODES))
@@ -191,6 +191,24 @@ class DeviceCSR:
         torch.cumsum(torch.bincount(trow, minlength=n_cols), 0, out=ptr[1:])
         return DeviceCSR(ptr, (keys - trow * n_rows).to(torch.int32), self.val[order], (n_cols, n_rows), self.device,
                          self.chunk_nnz)
+
+    def lockstep_slabs(self, f, limit):
+        """[(row0, row1, DeviceCSR of those rows)] and ONE workspace all of them fit: contiguous row slabs whose
+        lock-step CG workspace stays within `limit` bytes (cached)."""
+        key = ("slabs", f, limit)
+        hit = self._ws.get(key)
+        if hit is None:
+            n = self.shape[0]
+            per_row = max(1, lib.als_half_sweep_cg_workspace_bytes(n, self.n_slots, f) // max(n, 1))
+            rows = max(1, min(n, int(limit // per_row)))
+            while True:
+                slabs = [(r0, min(n, r0 + rows), self.row_range(r0, min(n, r0 + rows))) for r0 in range(0, n, rows)]
+                need = max(lib.als_half_sweep_cg_workspace_bytes(s.shape[0], s.n_slots, f) for _, _, s in slabs)
+                if need <= limit or rows == 1:
+                    break
+                rows = max(1, rows * 3 // 4)          # slots of long rows pushed a slab over the limit
+            hit = self._ws[key] = (slabs, torch.empty(need, dtype=torch.uint8, device=self.device))
+        return hit
 
     def workspace_cg(self, f):
         ws = self._ws.get(("cg", f))
@@ -328,12 +346,19 @@ def half_sweep(csr, Yopp, gram_cache, Xown, alpha, absdiff=None, info=None, opts
     return absdiff
 
 
-def half_sweep_cg(csr, Yopp, gram_cache, Xown, alpha, cg_steps, absdiff=None, info=None, form="auto", opts=None):
+LOCKSTEP_WS_LIMIT = 8 << 30     # bytes of lock-step CG workspace beyond which the rows are swept slab by slab
+
+
+def half_sweep_cg(csr, Yopp, gram_cache, Xown, alpha, cg_steps, absdiff=None, info=None, form="auto", opts=None,
+                  _ws=None):
     """One half-sweep by `cg_steps` conjugate-gradient steps per row, warm-started at the current
     rows of Xown (updated in place).  Same contract as half_sweep otherwise; 1 <= f <= 256.
     form: "matrix" - one gather pass, the steps run on the row's formed matrix in registers;
     "lock_step" - cg_steps + 1 gather passes with all rows in lock step; "auto" - matrix for
-    f <= 128, lock_step above (see include/als_hip.h)."""
+    f <= 128, lock_step above (see include/als_hip.h).
+    The lock-step form keeps four f-vectors per row in its workspace (16 f bytes per row: 205 GB for 50 M rows at
+    f = 256).  When that exceeds LOCKSTEP_WS_LIMIT the rows are swept in contiguous slabs that share one workspace of
+    that size; rows are independent, so the factors are the same bits as from one call."""
     if form not in _lib.CG_FORMS:
         raise ValueError("form must be one of %s" % sorted(_lib.CG_FORMS))
     if not isinstance(csr, DeviceCSR):
@@ -357,7 +382,20 @@ def half_sweep_cg(csr, Yopp, gram_cache, Xown, alpha, cg_steps, absdiff=None, in
         raise ValueError("cg_steps must be in [1, 1024]")
     if absdiff is None:
         absdiff = torch.zeros(1, dtype=torch.float64, device=csr.device)
-    ws = csr.workspace_cg(f)
+    lock_step = form == "lock_step" or (form == "auto" and f > _lib.MAX_FACTORS_EXACT)
+    if _ws is None and lock_step and csr.shape[0] > 1 \
+            and lib.als_half_sweep_cg_workspace_bytes(csr.shape[0], csr.n_slots, f) > LOCKSTEP_WS_LIMIT:
+        slabs, ws = csr.lockstep_slabs(f, LOCKSTEP_WS_LIMIT)
+        parts = torch.zeros(len(slabs), dtype=torch.float64, device=csr.device)
+        for k, (r0, r1, sub) in enumerate(slabs):
+            Xs = Xown if sub.row_ids is not None else Xown[r0:r1]
+            half_sweep_cg(sub, Yopp, gram_cache, Xs, alpha, cg_steps, absdiff=parts[k:k + 1], info=info, form=form,
+                          opts=opts, _ws=ws)
+        torch.sum(parts, 0, keepdim=True, out=absdiff)           # slab order: a fixed order
+        return absdiff
+    ws = csr.workspace_cg(f) if _ws is None else _ws
+    if ws.numel() < lib.als_half_sweep_cg_workspace_bytes(csr.shape[0], csr.n_slots, f):
+        raise ValueError("shared workspace too small for this slab")
     with torch.cuda.device(csr.device):
         check(lib.als_half_sweep_cg_f32(
             _ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.val), csr.shape[0], _ptr(csr.row_ids), _ptr(csr.items),

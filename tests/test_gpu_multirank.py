@@ -17,6 +17,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _worker(rank, world, port, N, M, f, balance, out_dir):
+    import faulthandler
+    faulthandler.dump_traceback_later(100, exit=True)       # a stuck rank names the call it is stuck in
     sys.path.insert(0, ROOT)
     import recommender_amd as ra
     from recommender_amd import data
@@ -50,6 +52,7 @@ def _worker(rank, world, port, N, M, f, balance, out_dir):
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
 
 
 def _free_port():

@@ -1,0 +1,80 @@
+"""The persistent stream kernel for 64 < f <= 128 (row_kernel="stream") against the one-wave kernel and the oracle.
+
+Both kernels cut, multiply and solve in the same order, so their factors and |delta| must be the same bits; the
+oracle comparison (float64 restatement of reclibwh/core/ALS.py:70-118) bounds both.  Shapes cover rows longer than
+chunk_nnz (their chunk items stay on the one-wave kernel), empty rows, fewer rows than resident waves, and f < 128
+(masked row halves).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _csr(rng, N, M, avg, maxlen):
+    lens = np.minimum(rng.zipf(1.6, size=N) + rng.integers(0, 2 * avg, size=N), maxlen).astype(np.int64)
+    lens[rng.integers(0, N, size=max(N // 50, 1))] = 0
+    ptr = np.zeros(N + 1, dtype=np.int64)
+    np.cumsum(lens, out=ptr[1:])
+    ind = np.concatenate([np.sort(rng.choice(M, size=l, replace=False)) for l in lens]).astype(np.int32)
+    dat = (rng.integers(1, 11, size=ptr[-1]) * 0.5).astype(np.float32)
+    return ptr, ind, dat
+
+
+@pytest.mark.parametrize("f", [128, 96, 100, 68])
+@pytest.mark.parametrize("shape", [(3000, 5000, 2048), (1200, 2500, 128), (5, 400, 2048), (700, 300, 64)])
+def test_stream_equals_wave_and_oracle(f, shape):
+    import recommender_amd as ra
+    from oracle import c_oracle
+
+    N, M, chunk = shape
+    rng = np.random.default_rng(1000 * f + N)
+    ptr, ind, dat = _csr(rng, N, M, 40, M - 1)
+    Y0 = rng.normal(0, 1 / np.sqrt(f), size=(M, f)).astype(np.float32)
+    X0 = rng.normal(0, 1 / np.sqrt(f), size=(N, f)).astype(np.float32)
+    ref = c_oracle.half_sweep(ptr, ind, dat, Y0, X0, 0.01, 40.0, dtype=np.float64, nthreads=8)
+    csr = ra.DeviceCSR(ptr, ind, dat, (N, M), "cuda", chunk_nnz=chunk)
+    Y = torch.from_numpy(Y0).cuda()
+    gc = ra.gram(Y, 0.01)
+    out = {}
+    for rk in ("wave", "stream"):
+        for cg in (0, 3):
+            res = []
+            for _ in range(2):
+                X = torch.from_numpy(X0).cuda()
+                info = torch.zeros(1, dtype=torch.int32, device="cuda")
+                o = ra.ops.sweep_opts(row_kernel=rk)
+                if cg:
+                    d = ra.ops.half_sweep_cg(csr, Y, gc, X, 40.0, cg, info=info, form="matrix", opts=o)
+                else:
+                    d = ra.half_sweep(csr, Y, gc, X, 40.0, info=info, opts=o)
+                torch.cuda.synchronize()
+                assert int(info.item()) == 0
+                res.append((X.cpu().numpy(), float(d.item())))
+            assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1], "two runs differ"
+            out[(rk, cg)] = res[0]
+    scale = np.abs(ref).max()
+    assert np.abs(out[("stream", 0)][0] - ref).max() / scale < 1e-4      # the tolerance the factors are held to
+    for cg in (0, 3):
+        assert np.array_equal(out[("stream", cg)][0], out[("wave", cg)][0])
+        assert out[("stream", cg)][1] == out[("wave", cg)][1]
+
+
+def test_stream_rejects_what_it_cannot_run():
+    import recommender_amd as ra
+
+    rng = np.random.default_rng(3)
+    ptr, ind, dat = _csr(rng, 200, 300, 10, 100)
+    for f in (64, 20):
+        Y = torch.from_numpy(rng.normal(size=(300, f)).astype(np.float32)).cuda()
+        X = torch.zeros(200, f, device="cuda")
+        csr = ra.DeviceCSR(ptr, ind, dat, (200, 300), "cuda")
+        with pytest.raises(ValueError, match="STREAM"):
+            ra.half_sweep(csr, Y, ra.gram(Y, 0.1), X, 40.0, opts=ra.ops.sweep_opts(row_kernel="stream"))
+    f = 128
+    Y = torch.from_numpy(rng.normal(size=(300, f)).astype(np.float32)).cuda()
+    X = torch.zeros(200, f, device="cuda")
+    csr = ra.DeviceCSR(ptr, ind, dat, (200, 300), "cuda")
+    with pytest.raises(ValueError, match="STREAM"):
+        ra.half_sweep(csr, Y, ra.gram(Y, 0.1), X, 40.0, opts=ra.ops.sweep_opts(row_kernel="stream", accumulate="fp32"))
