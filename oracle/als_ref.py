@@ -87,7 +87,7 @@ def half_sweep_exact(indptr, indices, data, Yfix, Xold, lamb, alpha, rows=None):
     return Xp
 
 
-def half_sweep_cg(indptr, indices, data, Yfix, Xold, lamb, alpha, steps, rows=None, dtype=np.float64):
+def half_sweep_cg(indptr, indices, data, Yfix, Xold, lamb, alpha, steps, rows=None, dtype=np.float64, Y2=None):
     """Per row u, `steps` conjugate-gradient steps on A x = b, started at x = Xold[u], with
         A = Y2 + Yp^T diag(alpha rp) Yp + lamb I,  b = Yp^T (1 + alpha rp)      (ALS.py:82-86)
     A is never formed: A v = Y2 v + Yp^T (alpha rp * (Yp v)) + lamb v.
@@ -96,10 +96,12 @@ def half_sweep_cg(indptr, indices, data, Yfix, Xold, lamb, alpha, steps, rows=No
         repeat steps times:  Ap = A p;  a = rs / p.Ap;  x += a p;  r -= a Ap
                              rs' = r.r;  p = r + (rs'/rs) p;  rs = rs'
     A step with rs == 0 or p.Ap <= 0 changes nothing.  A row without stored entries has the
-    exact solution 0 and gets it.  Stored zeros are dropped (ALS.py:79)."""
+    exact solution 0 and gets it.  Stored zeros are dropped (ALS.py:79).
+    Y2: Yfix^T Yfix computed by the caller (tests at full size hand in only the rows of Yfix that the sampled
+    rows touch, and the Gram of the whole table)."""
     Yfix = np.asarray(Yfix, dtype=dtype)
     Xp = np.array(Xold, dtype=dtype, copy=True)
-    Y2 = gram(Yfix).astype(dtype)
+    Y2 = (gram(Yfix) if Y2 is None else np.asarray(Y2)).astype(dtype)
     lamb = dtype(lamb); alpha = dtype(alpha)
     it = range(Xp.shape[0]) if rows is None else rows
     for u in it:

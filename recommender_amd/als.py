@@ -92,11 +92,9 @@ def run_als_epoch(csr, X, Y, cache, alpha, absdiff=None, info=None, backend=ops,
 
 def _host_staged(T, group):
     """RCCL ("nccl") moves device tensors directly and in stream order.  Any other backend (gloo in
-    tests and one-GPU rehearsals) gets host tensors.  ALS_COLLECTIVES_DEVICE=1 hands device tensors to
-    every backend (diagnosis of gloo's device path only)."""
-    import os
-    if os.environ.get("ALS_COLLECTIVES_DEVICE") == "1":
-        return False
+    tests and one-GPU rehearsals) gets host tensors: gloo's device path never returns from a collective
+    issued under a side stream that waits for a kernel on the default stream - with one rank as with
+    two, and with nothing of this package involved (tools/gloo_device_probe.py, variants C and D)."""
     return T.is_cuda and torch.distributed.get_backend(group) != "nccl"
 
 
@@ -188,7 +186,7 @@ class ALSEngine:
     """
 
     def __init__(self, csr_users, csr_items, X, Y, lamb, alpha, user_bounds=None, item_bounds=None, group=None,
-                 backend=ops, overlap_chunks=None, solver="auto", cg_steps=3, cg_form="auto"):
+                 backend=ops, overlap_chunks=None, solver="auto", cg_steps=10, cg_form="auto"):
         self.group = group
         self.backend = backend      # the HIP operators; tests inject a CPU stand-in to exercise the sharding logic
         self.world = torch.distributed.get_world_size(group) if group is not None else 1

@@ -31,7 +31,9 @@ DEFAULTS = dict(f=20,           # ALS.json.template:26 (the reference's layer wi
                                     # that still enter the Gram (ALS.py:243, ALS.py:456)
                 chunk_nnz=2048,
                 solver="auto",      # "cholesky" (exact, f <= 128), "cg", or "auto" = exact where it exists
-                cg_steps=3,         # conjugate-gradient steps per row and half-sweep when solver is "cg"
+                cg_steps=10,        # conjugate-gradient steps per row and half-sweep when solver is "cg": the count
+                                    # at which 15 iterations give the exact solve's MAP@200 / precision@10 / RMSE
+                                    # to 3 decimals on the ml-latest-small-shaped configuration (3 and 6 do not)
                 med_score=3.0,      # ALS.py:402
                 eval_lim=200)       # EvalProto.py:22
 

@@ -4,6 +4,10 @@ walk the whole input: sampled rows (the longest ones included, which are the row
 chunks) against the float64 oracle, bit-for-bit repeatability, row shards = whole, the sum of the
 per-row changes, and the fused top-k against a selection done by torch on the same scores.
 
+The same on one GPU's eighth of the 1 B-entry matrix (1.25 M users x 1 M items, 125 M entries, f = 128: exact and
+conjugate-gradient solves) and on a slice of the 4 B-entry one (all 5 M items, f = 256: conjugate gradients, the
+formed-matrix form over 4 wavefronts and the lock-step form swept in row slabs).
+
 Bounds: factors 1e-4 relative (max-abs error over the sample / max-abs value), the north-star
 bar; 2e-4 for three conjugate-gradient steps (a truncated iteration carries the float32 input
 rounding through every step; the same bound as the small CG tests)."""
@@ -52,7 +56,7 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-def _check_side(c2, csr_triplet, shape, fixed, own, seed):
+def _check_side(c2, csr_triplet, shape, fixed, own, seed, min_longest=2 * 2048):
     ra = c2["ra"]
     ptr_d, col_d, val_d = csr_triplet
     csr = ra.DeviceCSR(ptr_d, col_d, val_d, shape, "cuda")
@@ -68,7 +72,7 @@ def _check_side(c2, csr_triplet, shape, fixed, own, seed):
     # sampled rows against the float64 oracle: the longest rows (cut into chunks) are in the sample
     ptr, col, val = (t.cpu().numpy() for t in csr_triplet)
     rows, lens = _sample_rows(ptr, np.random.default_rng(seed), 300, 25)
-    assert lens[rows].max() > 2 * 2048                      # rows of several chunks
+    assert lens[rows].max() > min_longest                   # rows of several chunks
     sp, sc, sv = _sub_csr(ptr, col, val, rows)
     ref = c_oracle.half_sweep(sp, sc, sv, fixed.astype(np.float64), own[rows].astype(np.float64), LAMB, ALPHA,
                               dtype=np.float64, nthreads=8)
@@ -100,6 +104,88 @@ def test_c2_user_and_item_half_sweeps_at_full_size(c2):
     N, M = c2["N"], c2["M"]
     X1 = _check_side(c2, c2["U"], (N, M), c2["Y0"], c2["X0"], seed=1)
     _check_side(c2, c2["Ut"], (M, N), X1, c2["Y0"], seed=2)
+
+
+def _device_factors(n, f, seed):
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    return (torch.randn((n, f), generator=g, device="cuda") / f ** 0.5).cpu().numpy()
+
+
+def test_c3_shard_user_and_item_half_sweeps_at_full_size():
+    """One GPU's eighth of the 10 M x 1 M matrix at f = 128: both factor tables exceed the caches, rows are short
+    (100 entries a user), and with 1.25 M rows every resident wavefront of the stream kernel has its own."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import recommender_amd as ra
+    from recommender_amd import data
+    wl = data.WORKLOADS["c3_shard_syn"]
+    N, M, f = wl["n_users"], wl["n_items"], wl["f"]
+    U, Ut = data.synth_matrix(N, M, wl["nnz"], seed=4321, device="cuda")
+    ctx = dict(ra=ra)
+    X0, Y0 = _device_factors(N, f, 11), _device_factors(M, f, 12)
+    X1 = _check_side(ctx, U, (N, M), Y0, X0, seed=3, min_longest=64)
+    del U
+    _check_side(ctx, Ut, (M, N), X1, Y0, seed=4, min_longest=2048)
+
+
+def test_c4_slice_cg_forms_at_f256():
+    """A slice of one GPU's eighth of the 50 M x 5 M matrix (every item, 1/20 of the shard's users) at f = 256: three
+    conjugate-gradient steps in the formed-matrix form (a row's tiles over 4 wavefronts) and in the lock-step form
+    swept in row slabs that share one bounded workspace; sampled rows (the longest included) against the float64
+    restatement, which gets the rows of the item table that the sample touches and the Gram of the whole table."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import recommender_amd as ra
+    from recommender_amd import data, ops
+    from recommender_amd.als import balanced_ranges
+    N, M, nnz, f = 312_500, 5_000_000, 25_000_000, 256
+    keys, r = data.synth_pairs(N, M, nnz, 99, "cuda")
+    U = data.csr_from_sorted_keys(keys, r, N, M)
+    del keys, r
+    g = torch.Generator(device="cuda"); g.manual_seed(21)
+    Y = torch.randn((M, f), generator=g, device="cuda") / f ** 0.5
+    X0 = torch.randn((N, f), generator=g, device="cuda") / f ** 0.5
+    csr = ra.DeviceCSR(U[0], U[1], U[2], (N, M), "cuda")
+    gc = ra.gram(Y, LAMB)
+    ptr, col, val = (t.cpu().numpy() for t in U)
+    rows, lens = _sample_rows(ptr, np.random.default_rng(8), 60, 10)
+    sp, sc, sv = _sub_csr(ptr, col, val, rows)
+    used, sc_local = np.unique(sc, return_inverse=True)
+    Ysub = Y[torch.from_numpy(used.astype(np.int64)).cuda()].double().cpu().numpy()
+    Y2 = (Y.double().T @ Y.double()).cpu().numpy()
+    ref = als_ref.half_sweep_cg(sp, sc_local, sv, Ysub, X0[torch.from_numpy(rows).cuda()].double().cpu().numpy(),
+                                LAMB, ALPHA, 3, Y2=Y2)
+    sel = torch.from_numpy(rows).cuda()
+    out = {}
+    for form in ("matrix", "lock_step"):
+        info = torch.zeros(1, dtype=torch.int32, device="cuda")
+        X = X0.clone()
+        old = ops.LOCKSTEP_WS_LIMIT
+        ops.LOCKSTEP_WS_LIMIT = 96 << 20          # 4 f-vectors a row: 4 KB a row at f = 256 -> slabs of ~24 000 rows
+        try:
+            d = ra.half_sweep_cg(csr, Y, gc, X, ALPHA, 3, info=info, form=form)
+            X2 = X0.clone()
+            d2 = ra.half_sweep_cg(csr, Y, gc, X2, ALPHA, 3, form=form)
+        finally:
+            ops.LOCKSTEP_WS_LIMIT = old
+        assert int(info.item()) == 0
+        assert torch.equal(X, X2) and float(d.item()) == float(d2.item())          # bit-for-bit repeatable
+        ref_d = (X0.double() - X.double()).abs().sum()
+        assert float(d.item()) == pytest.approx(float(ref_d.item()), rel=1e-6)
+        got = X[sel].cpu().numpy().astype(np.float64)
+        assert _rel(got, ref) < 2e-4, (form, _rel(got, ref))
+        out[form] = X
+    # the slabs' factors are those of one call with the whole workspace
+    X3 = X0.clone()
+    ra.half_sweep_cg(csr, Y, gc, X3, ALPHA, 3, form="lock_step")
+    assert torch.equal(out["lock_step"], X3)
+    # two row shards (balanced by entries) give the same bits as the whole, in either form
+    b = [int(x) for x in balanced_ranges(ptr, 2)]
+    for form in ("matrix", "lock_step"):
+        X4 = X0.clone()
+        for r0, r1 in zip(b[:-1], b[1:]):
+            ra.half_sweep_cg(csr.row_range(r0, r1), Y, gc, X4[r0:r1], ALPHA, 3, form=form)
+        assert torch.equal(out[form], X4)
 
 
 def test_c5_fused_topk_at_one_million_items():

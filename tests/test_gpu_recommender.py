@@ -250,6 +250,70 @@ def test_c1_full_training_metrics_to_three_decimals(ra):
     assert abs(rg - ro) < 5e-4, (rg, ro)
 
 
+def _c1_split():
+    from recommender_amd import data
+    N, M = 610, 9724
+    keys, r = data.synth_pairs(N, M, 100836, seed=1234, device="cpu")
+    keys, r = keys.numpy(), r.numpy().astype(np.float64)
+    rng = np.random.default_rng(0)
+    test = rng.random(len(keys)) < 0.2
+
+    def mat(mask):
+        m = sps.csr_matrix((r[mask], (keys[mask] // M, keys[mask] % M)), shape=(N, M)); m.sort_indices(); return m
+    return N, M, mat(~test), mat(test)
+
+
+def _precision_at_10(idx_rows, users, tr, te, filt):
+    hits = []
+    for k, u in enumerate(users):
+        trn = set(tr.indices[tr.indptr[u]:tr.indptr[u + 1]])
+        row = [i for i in idx_rows[k] if not (filt and i in trn)][:10]
+        tst = set(te.indices[te.indptr[u]:te.indptr[u + 1]])
+        hits.append(sum(1 for i in row if i in tst) / 10.0)
+    return float(np.mean(hits))
+
+
+CG_STEPS_DEFAULT = 10
+
+
+@pytest.mark.parametrize("cg_steps", [CG_STEPS_DEFAULT, 2 * CG_STEPS_DEFAULT])
+def test_c1_cg_training_metrics_to_three_decimals(ra, cg_steps):
+    """The conjugate-gradient solver at metric level, on BASELINE configs[0] at its own size: 15 iterations with
+    `cg_steps` warm-started steps per row (10 is the default of RecommenderALS and of the benchmark's CG lines;
+    3 steps miss MAP@200 by 5e-3 and 6 by 2e-3 here, 8 miss precision@10 by 6e-4)
+    against the EXACT float64 solve of reclibwh/core/ALS.py:82-86 run from the same init.  The truncated iteration
+    does not reproduce the exact factors (no factor bound here); what must hold is what a user of the model sees:
+    MAP@200, precision@10 and held-out RMSE identical to 3 decimals."""
+    from recommender_amd import metrics
+    f, lamb, alpha, iters = 20, 0.01, 40.0, 15
+    N, M, tr, te = _c1_split()
+    rec = ra.RecommenderALS(mode="train", n_users=N, n_items=M,
+                            als_kwargs={"f": f, "lamb": lamb, "alpha": alpha, "epochs": iters, "solver": "cg",
+                                        "cg_steps": cg_steps})
+    rec.input_data((tr, te))
+    rec.train(evaluate=False)
+    X0, Y0 = als_ref.init_factors(N, M, f, "ref")
+    trt = sps.csr_matrix(tr.T); trt.sort_indices()
+    Xo, Yo = X0, Y0
+    for _ in range(iters):
+        Xo = c_oracle.half_sweep(tr.indptr, tr.indices, tr.data, Yo, Xo, lamb, alpha, nthreads=8)
+        Yo = c_oracle.half_sweep(trt.indptr, trt.indices, trt.data, Xo, Yo, lamb, alpha, nthreads=8)
+    users = metrics.users_to_test(tr)
+    score = rec.evaluate(users)
+    oidx, _ = als_ref.recommend_full(Xo, Yo, users)
+    oscore = als_ref.map_at_k(oidx, (te.indptr, te.indices, te.data), (tr.indptr, tr.indices, tr.data), users, 3.0, 200)
+    gidx, _ = rec.recommend(users, k=10, filter_rated=True)
+    pg, po = _precision_at_10(gidx, users, tr, te, False), _precision_at_10(oidx, users, tr, te, True)
+    tu, ti = te.nonzero()
+    rg = metrics.rmse(rec.predict(tu, ti), np.ones(len(tu)))
+    ro = als_ref.rmse(np.einsum("ij,ij->i", Xo[tu], Yo[ti]), np.ones(len(tu)))
+    print("cg_steps=%d: MAP@200 %.5f vs %.5f, precision@10 %.5f vs %.5f, RMSE %.5f vs %.5f"
+          % (cg_steps, score, oscore, pg, po, rg, ro))
+    assert abs(score - oscore) < 5e-4, (score, oscore)
+    assert abs(pg - po) < 5e-4, (pg, po)
+    assert abs(rg - ro) < 5e-4, (rg, ro)
+
+
 def _two_call(ra, X, Y, users, k, ex):
     return ra.ops.recommend_topk(X, Y, users, k, exclude_csr=ex, fused=False)
 
