@@ -263,7 +263,8 @@ int32_t als_half_sweep_cg_f32(const int64_t *rowptr, const int32_t *col, const f
  * als_topk_rows_f32     per row of `scores`, the k largest entries in descending order, ties by
  *                       ascending column (the reference does a full numpy argsort of every row,
  *                       RecAlgos.py:32; its consumers keep the first 200).  If ex_rowptr/ex_col
- *                       (a CSR with n_rows rows) are given, those columns of each row are set to
+ *                       (a CSR; row ex_row_ids[r] for score row r, or row r if ex_row_ids is NULL) are
+ *                       given, those columns of each row are set to
  *                       -inf first, in place (the "drop rated items" filter of
  *                       reclibwh/serving/RecommenderService.py:16-29).  1 <= k <= min(1024, M).
  * als_predict_pairs_f32 out[p] = <X[u[p]], Y[i[p]]> (the ALS Keras model's output, model
@@ -275,7 +276,8 @@ int32_t als_half_sweep_cg_f32(const int64_t *rowptr, const int32_t *col, const f
 int32_t als_scores_f32(const float *X, int64_t ldx, const int64_t *user_ids, int64_t nu, const float *Y, int64_t ldy,
                        int64_t M, int32_t f, float *scores, int64_t lds, void *stream);
 int32_t als_topk_rows_f32(float *scores, int64_t lds, int64_t n_rows, int64_t M, const int64_t *ex_rowptr,
-                          const int32_t *ex_col, int32_t k, int32_t *idx_out, float *score_out, void *stream);
+                          const int32_t *ex_col, const int64_t *ex_row_ids, int32_t k, int32_t *idx_out, float *score_out,
+                          void *stream);
 /* Fused top-k - the whole of SimpleMFRecAlgo.recommend (RecAlgos.py:20-32) followed by the
  * "drop rated items, keep the best" filter of RecommenderService.py:16-29, without materialising
  * the [nu, M] score matrix: the first S items (S = max(16 384, 16 k)) are scored and selected
@@ -285,15 +287,18 @@ int32_t als_topk_rows_f32(float *scores, int64_t lds, int64_t n_rows, int64_t M,
  * list of 8192 slots per user); after each range the candidates are ordered (score descending,
  * ties by ascending item id) and cut back to k, which tightens the threshold for the next range.
  * Same result as the two-call path.
- * ex_rowptr/ex_col: optional CSR (nu rows, sorted columns) of items to exclude per user.
+ * ex_rowptr/ex_col: optional CSR (sorted columns) of items to exclude per user.  ex_by_user_id == 0: it has nu
+ * rows, row u for output row u.  ex_by_user_id != 0: it is indexed by user id - output row u reads row
+ * user_ids[u] - so the training matrix's own rowptr/col serve as they lie on the device, for any block of users
+ * (the "drop rated items" filter of RecommenderService.py:16-29 with nothing built per request).
  * overflow_out [device] one int32: number of candidates that did not fit a user's list; if it is
  * not 0 the outputs are not valid and the caller must use the two-call path for these users.
  * 1 <= k <= min(1024, M); nu <= 65535*64. */
 size_t als_recommend_topk_workspace_bytes(int64_t nu, int64_t M, int32_t k);
 int32_t als_recommend_topk_f32(const float *X, int64_t ldx, const int64_t *user_ids, int64_t nu, const float *Y,
                                int64_t ldy, int64_t M, int32_t f, int32_t k, const int64_t *ex_rowptr,
-                               const int32_t *ex_col, int32_t *idx_out, float *score_out, int32_t *overflow_out,
-                               void *workspace, size_t ws_bytes, void *stream);
+                               const int32_t *ex_col, int32_t ex_by_user_id, int32_t *idx_out, float *score_out,
+                               int32_t *overflow_out, void *workspace, size_t ws_bytes, void *stream);
 int32_t als_predict_pairs_f32(const float *X, int64_t ldx, const float *Y, int64_t ldy, const int64_t *u,
                               const int64_t *i, int64_t n, int32_t f, float *out, void *stream);
 int32_t als_normalize_rows_f32(const float *E, int64_t lde, int64_t n, int32_t f, float *out, int64_t ldo,

@@ -40,10 +40,10 @@ SIGNATURES = {
     "als_gram_partials_f32": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i64, c_vp, c_vp, c_sz, c_vp]),
     "als_gram_finalize_f32": (c_i32, [c_vp, c_i64, c_i32, c_f32, c_vp, c_vp, c_vp]),
     "als_scores_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_vp]),
-    "als_topk_rows_f32": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
+    "als_topk_rows_f32": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "als_recommend_topk_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32]),
-    "als_recommend_topk_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp,
-                                       c_vp, c_vp, c_sz, c_vp]),
+    "als_recommend_topk_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp,
+                                       c_vp, c_vp, c_vp, c_sz, c_vp]),
     "als_predict_pairs_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),
     "als_normalize_rows_f32": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_vp]),
     "als_half_sweep_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32]),

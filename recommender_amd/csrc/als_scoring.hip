@@ -64,12 +64,14 @@ struct CandArgs {
     int32_t *overflow;
     const int64_t *ex_rowptr;
     const int32_t *ex_col;
+    const int64_t *ex_rows;     // CSR row of output row u (NULL: u itself)
     int32_t cap, k;
 };
 
 __device__ __forceinline__ bool excluded_item(const CandArgs &c, const int64_t u, const int item) {
     if (!c.ex_rowptr) return false;
-    int64_t lo = c.ex_rowptr[u], hi = c.ex_rowptr[u + 1];
+    const int64_t er = c.ex_rows ? c.ex_rows[u] : u;
+    int64_t lo = c.ex_rowptr[er], hi = c.ex_rowptr[er + 1];
     while (lo < hi) {          // the exclusion rows are sorted (canonical CSR)
         const int64_t mid = (lo + hi) >> 1;
         const int v = c.ex_col[mid];
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256) void scores_kernel(const float *__restrict__ X
                 for (int b = 0; b < 4; ++b) {
                     const int64_t i = i0 + 16 * b + j;
                     const float sc = acc[a][b][r];
-                    if (i < M && sc > tau && !excluded_item(cand, u, (int)i)) {
+                    if (i < M && sc > tau) {       // excluded items are dropped when the candidates are ordered
                         const int pos = atomicAdd(&cand.count[u], 1);      // integer: which slot, not what value
                         if (pos < cand.cap) {
                             cand.score[u * cand.cap + pos] = sc;
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void scores_split_kernel(const float *__res
                     for (int it = 0; it < 2; ++it) {
                         const int64_t i = item_begin + t * SB_ITEMS + it * 16 + j;
                         const float sc = acc[it][a][r];
-                        if (i < M && sc > tau[a][r] && !excluded_item(cand, u, (int)i)) {
+                        if (i < M && sc > tau[a][r]) {      // excluded items are dropped when the candidates are ordered
                             flush();             // only a lane's second hit within one stage waits here
                             pend = true;
                             pend_pos = atomicAdd(&cand.count[u], 1);      // integer: which slot, not what value
@@ -414,7 +416,8 @@ constexpr int TOPK_MAX = 1024;
 
 __global__ __launch_bounds__(256) void topk_rows_kernel(float *__restrict__ S, const int64_t lds, const int64_t M,
                                                        const int64_t *__restrict__ ex_rowptr,
-                                                       const int32_t *__restrict__ ex_col, const int k,
+                                                       const int32_t *__restrict__ ex_col,
+                                                       const int64_t *__restrict__ ex_rows, const int k,
                                                        int32_t *__restrict__ idx_out, float *__restrict__ score_out,
                                                        const int64_t out_stride) {
     __shared__ uint32_t hist[256];
@@ -427,7 +430,8 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(float *__restrict__ S, c
 
     // 0. excluded items (e.g. already rated, RecommenderService.py:16-29) drop to -inf
     if (ex_rowptr) {
-        const int64_t s = ex_rowptr[blockIdx.x], e = ex_rowptr[blockIdx.x + 1];
+        const int64_t er = ex_rows ? ex_rows[blockIdx.x] : (int64_t)blockIdx.x;
+        const int64_t s = ex_rowptr[er], e = ex_rowptr[er + 1];
         for (int64_t q = s + tid; q < e; q += 256) {
             const int c = ex_col[q];
             if (c >= 0 && c < M) row[c] = -INFINITY;
@@ -546,21 +550,28 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(float *__restrict__ S, c
 constexpr int CAND_CAP = 8192;
 // idx_out == nullptr: the first k go back to the head of the candidate row and the row's count
 // becomes k (the row's threshold, slot k-1, tightens for the items still to come).
-__global__ __launch_bounds__(256) void select_candidates_kernel(float *__restrict__ cscore, int32_t *__restrict__ citem,
-                                                               int32_t *__restrict__ count, const int cap,
-                                                               const int k, int32_t *__restrict__ idx_out,
+__global__ __launch_bounds__(256) void select_candidates_kernel(const CandArgs c, int32_t *__restrict__ idx_out,
                                                                float *__restrict__ score_out) {
     __shared__ uint32_t key[CAND_CAP];
     __shared__ int32_t item[CAND_CAP];
+    float *__restrict__ cscore = c.score;
+    int32_t *__restrict__ citem = c.item;
+    int32_t *__restrict__ count = c.count;
+    const int cap = c.cap, k = c.k;
     const int tid = threadIdx.x;
     const int64_t row = blockIdx.x;
     const int n = min(count[row], cap);
     int n2 = 1;
     while (n2 < n) n2 <<= 1;
+    // Slots [0, k) hold the best of the earlier ranges, exclusions applied.  The score kernel appends every score
+    // above the threshold; a user's excluded items among them (at most as many as it has) are dropped here, one
+    // binary search per thread, instead of behind every hit inside the matrix-core loop.
     for (int q = tid; q < n2; q += 256) {
-        const bool ok = q < n;
+        bool ok = q < n;
+        const int32_t it = ok ? citem[row * cap + q] : INT32_MAX;
+        if (ok && q >= k && excluded_item(c, row, it)) ok = false;
         key[q] = ok ? order_key(cscore[row * cap + q]) : 0u;
-        item[q] = ok ? citem[row * cap + q] : INT32_MAX;
+        item[q] = ok ? it : INT32_MAX;
     }
     __syncthreads();
     for (int size = 2; size <= n2; size <<= 1) {
@@ -714,8 +725,8 @@ size_t als_recommend_topk_workspace_bytes(int64_t nu, int64_t M, int32_t k) {
 
 int32_t als_recommend_topk_f32(const float *X, int64_t ldx, const int64_t *user_ids, int64_t nu, const float *Y,
                                int64_t ldy, int64_t M, int32_t f, int32_t k, const int64_t *ex_rowptr,
-                               const int32_t *ex_col, int32_t *idx_out, float *score_out, int32_t *overflow_out,
-                               void *workspace, size_t ws_bytes, void *stream) {
+                               const int32_t *ex_col, int32_t ex_by_user_id, int32_t *idx_out, float *score_out,
+                               int32_t *overflow_out, void *workspace, size_t ws_bytes, void *stream) {
     if (!X || !Y || !idx_out || !score_out || !overflow_out || !workspace)
         return als_fail_(ALS_ERR_INVALID_ARG, "als_recommend_topk_f32: null pointer");
     if (nu < 1 || M < 1 || M > INT32_MAX || f < 1 || ldx < f || ldy < f)
@@ -729,6 +740,8 @@ int32_t als_recommend_topk_f32(const float *X, int64_t ldx, const int64_t *user_
     const size_t need = als_recommend_topk_workspace_bytes(nu, M, k);
     if (ws_bytes < need) return als_fail_(ALS_ERR_WORKSPACE, "top-k workspace too small: %zu < %zu", ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
+    // exclusion CSR indexed by user id: output row u reads CSR row user_ids[u] (no user_ids: u, as before)
+    const int64_t *ex_rows = (ex_rowptr && ex_by_user_id) ? user_ids : nullptr;
     const int64_t S = fused_subset_items(M, k);
     char *ws = (char *)workspace;
     float *sub = (float *)ws; ws += align256((size_t)nu * S * sizeof(float));
@@ -737,18 +750,18 @@ int32_t als_recommend_topk_f32(const float *X, int64_t ldx, const int64_t *user_
     if (rc) return rc;
     if (S == M) {
         ALS_HIP_CHECK2(hipMemsetAsync(overflow_out, 0, sizeof(int32_t), st));
-        return als_topk_rows_f32(sub, S, nu, S, ex_rowptr, ex_col, k, idx_out, score_out, stream);
+        return als_topk_rows_f32(sub, S, nu, S, ex_rowptr, ex_col, ex_rows, k, idx_out, score_out, stream);
     }
     CandArgs c;
     c.score = (float *)ws; ws += align256((size_t)nu * CAND_CAP * 4);
     c.item = (int32_t *)ws; ws += align256((size_t)nu * CAND_CAP * 4);
     c.count = (int32_t *)ws;
-    c.overflow = overflow_out; c.ex_rowptr = ex_rowptr; c.ex_col = ex_col; c.cap = CAND_CAP; c.k = k;
+    c.overflow = overflow_out; c.ex_rowptr = ex_rowptr; c.ex_col = ex_col; c.ex_rows = ex_rows; c.cap = CAND_CAP; c.k = k;
     ALS_HIP_CHECK2(hipMemsetAsync(overflow_out, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, st, c.count, nu, k);
     ALS_HIP_CHECK2(hipGetLastError());
-    hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)nu), dim3(256), 0, st, sub, S, S, ex_rowptr, ex_col, k, c.item,
-                       c.score, (int64_t)CAND_CAP);
+    hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)nu), dim3(256), 0, st, sub, S, S, ex_rowptr, ex_col, ex_rows, k,
+                       c.item, c.score, (int64_t)CAND_CAP);
     ALS_HIP_CHECK2(hipGetLastError());
     // 2. the later items, range by range: score tiles are compared with the user's threshold in
     //    registers, never stored; then each user's candidates are ordered and cut back to k
@@ -767,8 +780,8 @@ int32_t als_recommend_topk_f32(const float *X, int64_t ldx, const int64_t *user_
                                (int64_t)0, begin, c);
         ALS_HIP_CHECK2(hipGetLastError());
         const bool last = end == M;
-        hipLaunchKernelGGL(select_candidates_kernel, dim3((unsigned)nu), dim3(256), 0, st, c.score, c.item, c.count, CAND_CAP,
-                           k, last ? idx_out : nullptr, last ? score_out : nullptr);
+        hipLaunchKernelGGL(select_candidates_kernel, dim3((unsigned)nu), dim3(256), 0, st, c, last ? idx_out : nullptr,
+                           last ? score_out : nullptr);
         ALS_HIP_CHECK2(hipGetLastError());
         begin = end;
     }
@@ -776,7 +789,8 @@ int32_t als_recommend_topk_f32(const float *X, int64_t ldx, const int64_t *user_
 }
 
 int32_t als_topk_rows_f32(float *scores, int64_t lds, int64_t n_rows, int64_t M, const int64_t *ex_rowptr,
-                          const int32_t *ex_col, int32_t k, int32_t *idx_out, float *score_out, void *stream) {
+                          const int32_t *ex_col, const int64_t *ex_row_ids, int32_t k, int32_t *idx_out, float *score_out,
+                          void *stream) {
     if (!scores || !idx_out || !score_out) return als_fail_(ALS_ERR_INVALID_ARG, "als_topk_rows_f32: null pointer");
     if (n_rows < 1 || M < 1 || lds < M || M > INT32_MAX)
         return als_fail_(ALS_ERR_INVALID_ARG, "als_topk_rows_f32: bad sizes");
@@ -785,7 +799,7 @@ int32_t als_topk_rows_f32(float *scores, int64_t lds, int64_t n_rows, int64_t M,
     if ((ex_rowptr == nullptr) != (ex_col == nullptr))
         return als_fail_(ALS_ERR_INVALID_ARG, "als_topk_rows_f32: pass both exclusion arrays or neither");
     hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, scores, lds, M,
-                       ex_rowptr, ex_col, k, idx_out, score_out, (int64_t)k);
+                       ex_rowptr, ex_col, ex_rowptr ? ex_row_ids : nullptr, k, idx_out, score_out, (int64_t)k);
     ALS_HIP_CHECK2(hipGetLastError());
     return ALS_OK;
 }

@@ -439,10 +439,12 @@ def scores(X, Y, user_ids=None, M=None, out=None):
     return out[:nu, :M]
 
 
-def topk_rows(score_rows, k, exclude=None):
+def topk_rows(score_rows, k, exclude=None, exclude_rows=None):
     """Per row: the k largest scores, descending, ties by ascending column.  `exclude` =
-    (rowptr int64 [n_rows+1], col int32) device tensors: columns forced to -inf first (the score
-    rows are modified in place).  Returns (idx int32 [n, k], values float32 [n, k])."""
+    (rowptr int64, col int32) device tensors: columns forced to -inf first (the score rows are
+    modified in place).  Score row r takes CSR row r, or CSR row exclude_rows[r] (int64 device
+    tensor) when given - a CSR over all users then serves any block of them.
+    Returns (idx int32 [n, k], values float32 [n, k])."""
     _need(score_rows, torch.float32, "score_rows", 2)
     if score_rows.stride(1) != 1:
         raise ValueError("score rows must have unit inner stride")
@@ -455,13 +457,22 @@ def topk_rows(score_rows, k, exclude=None):
         ex_ptr, ex_col = exclude
         _index(ex_ptr, torch.int64, "exclude rowptr")
         _index(ex_col, torch.int32, "exclude col")
-        if ex_ptr.shape[0] != n + 1:
+        _same_device(score_rows, ex_ptr, ex_col, exclude_rows)
+        if exclude_rows is not None:
+            _index(exclude_rows, torch.int64, "exclude_rows")
+            if exclude_rows.shape[0] != n:
+                raise ValueError("exclude_rows must have one entry per score row")
+            if n and (int(exclude_rows.min()) < 0 or int(exclude_rows.max()) + 1 >= ex_ptr.shape[0]):
+                raise ValueError("exclude_rows points outside the exclusion CSR")
+        elif ex_ptr.shape[0] != n + 1:
             raise ValueError("exclude rowptr must have n_rows + 1 entries")
+    elif exclude_rows is not None:
+        raise ValueError("exclude_rows without exclude")
     idx = torch.empty((n, k), dtype=torch.int32, device=score_rows.device)
     val = torch.empty((n, k), dtype=torch.float32, device=score_rows.device)
     with torch.cuda.device(score_rows.device):
-        check(lib.als_topk_rows_f32(_ptr(score_rows), score_rows.stride(0), n, M, _ptr(ex_ptr), _ptr(ex_col), k,
-                                    _ptr(idx), _ptr(val), _stream()), "als_topk_rows_f32")
+        check(lib.als_topk_rows_f32(_ptr(score_rows), score_rows.stride(0), n, M, _ptr(ex_ptr), _ptr(ex_col),
+                                    _ptr(exclude_rows), k, _ptr(idx), _ptr(val), _stream()), "als_topk_rows_f32")
     return idx, val
 
 
@@ -493,21 +504,28 @@ def normalize_rows(E, out=None):
     return out
 
 
-def _block_exclusions(exclude_csr, users_host, device):
-    """Device CSR (rowptr int64, col int32) of the excluded items of the users in users_host."""
+def device_exclusions(exclude_csr, device):
+    """(rowptr int64, col int32) device tensors of an exclusion CSR over ALL users, from host numpy arrays, device
+    tensors or a DeviceCSR (its own arrays, nothing copied)."""
+    if isinstance(exclude_csr, DeviceCSR):
+        return exclude_csr.rowptr, exclude_csr.col
     ptr, col = exclude_csr
-    lens = (ptr[users_host + 1] - ptr[users_host]).astype(np.int64)
-    p = np.zeros(len(users_host) + 1, dtype=np.int64); np.cumsum(lens, out=p[1:])
-    cols = np.concatenate([col[ptr[u]:ptr[u + 1]] for u in users_host]) if p[-1] else np.zeros(0, np.int32)
-    return (torch.from_numpy(p).to(device),
-            torch.from_numpy(np.ascontiguousarray(cols, dtype=np.int32)).to(device)
-            if p[-1] else torch.zeros(1, dtype=torch.int32, device=device))
+    if not torch.is_tensor(ptr):
+        ptr = torch.from_numpy(np.ascontiguousarray(ptr, dtype=np.int64))
+    if not torch.is_tensor(col):
+        col = torch.from_numpy(np.ascontiguousarray(col, dtype=np.int32))
+    ptr = ptr.to(device=device, dtype=torch.int64).contiguous()
+    col = col.to(device=device, dtype=torch.int32).contiguous()
+    if col.numel() == 0:
+        col = torch.zeros(1, dtype=torch.int32, device=device)       # a pointer the library accepts; never read
+    return ptr, col
 
 
 def recommend_topk(X, Y, users, k, M=None, exclude_csr=None, block_users=4096, fused=True):
     """Top-k items for `users` (int64 device tensor), block_users users at a time.
-    exclude_csr: optional (rowptr, col) HOST numpy CSR over ALL users (sorted columns) whose
-    columns are filtered per user.  Returns (idx int32 [nu, k], scores [nu, k]).
+    exclude_csr: optional CSR over ALL users (sorted columns) whose columns are filtered per user: (rowptr, col) as
+    host numpy arrays or device tensors, or a DeviceCSR (the training matrix as it lies on the device).  The kernels
+    index it by user id; nothing is built per block.  Returns (idx int32 [nu, k], scores [nu, k]).
 
     fused=True: als_recommend_topk_f32 - only the first 16 384+ items of a block are materialised,
     the rest is filtered in the score kernel's registers.  A block whose candidate lists overflow
@@ -518,6 +536,7 @@ def recommend_topk(X, Y, users, k, M=None, exclude_csr=None, block_users=4096, f
     if Y.shape[1] != f or not (1 <= M <= Y.shape[0]):
         raise ValueError("factor counts differ or M out of range")
     _index(users, torch.int64, "users")
+    _same_device(X, Y, users)
     nu = users.shape[0]
     k = int(k)
     if not (1 <= k <= min(1024, M)):
@@ -526,7 +545,11 @@ def recommend_topk(X, Y, users, k, M=None, exclude_csr=None, block_users=4096, f
         raise ValueError("user id out of range")
     idx = torch.empty((nu, k), dtype=torch.int32, device=X.device)
     val = torch.empty((nu, k), dtype=torch.float32, device=X.device)
-    users_host = users.cpu().numpy() if exclude_csr is not None else None
+    ex = None
+    if exclude_csr is not None:
+        ex = device_exclusions(exclude_csr, X.device)
+        if nu and int(users.max()) + 1 >= ex[0].shape[0]:
+            raise ValueError("a user id lies outside the exclusion CSR")
     bu = min(block_users, max(nu, 1))
     buf = None
     blocks = [(s, min(nu, s + block_users)) for s in range(0, nu, block_users)]
@@ -535,10 +558,9 @@ def recommend_topk(X, Y, users, k, M=None, exclude_csr=None, block_users=4096, f
         ws = torch.empty(lib.als_recommend_topk_workspace_bytes(bu, M, k), dtype=torch.uint8, device=X.device)
         overflow = torch.zeros(len(blocks), dtype=torch.int32, device=X.device)
         for b, (s, e) in enumerate(blocks):
-            ex = _block_exclusions(exclude_csr, users_host[s:e], X.device) if exclude_csr is not None else None
             with torch.cuda.device(X.device):
                 check(lib.als_recommend_topk_f32(_ptr(X), ldx, _ptr(users[s:e]), e - s, _ptr(Y), ldy, M, f, k,
-                                                 _ptr(ex[0]) if ex else None, _ptr(ex[1]) if ex else None,
+                                                 _ptr(ex[0]) if ex else None, _ptr(ex[1]) if ex else None, 1,
                                                  _ptr(idx[s:e]), _ptr(val[s:e]), _ptr(overflow[b:b + 1]), _ptr(ws),
                                                  ws.numel(), _stream()), "als_recommend_topk_f32")
         redo = torch.nonzero(overflow).flatten().cpu().tolist()       # one synchronisation for all blocks
@@ -547,10 +569,9 @@ def recommend_topk(X, Y, users, k, M=None, exclude_csr=None, block_users=4096, f
     for b in redo:
         for s in range(blocks[b][0], blocks[b][1], rows_per):
             e = min(blocks[b][1], s + rows_per)
-            ex = _block_exclusions(exclude_csr, users_host[s:e], X.device) if exclude_csr is not None else None
             if buf is None:
                 buf = torch.empty((rows_per, M), dtype=torch.float32, device=X.device)
             sc = scores(X, Y, users[s:e], M, out=buf)
-            i_, v_ = topk_rows(sc, k, ex)
+            i_, v_ = topk_rows(sc, k, ex, users[s:e] if ex else None)
             idx[s:e] = i_; val[s:e] = v_
     return idx, val

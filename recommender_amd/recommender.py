@@ -61,6 +61,7 @@ class RecommenderALS:
         self.Utrain = self.Utest = None
         self.engine = None
         self._foldin_cache = None
+        self._exclusions = None
         self.start_epoch = 0
         self.trace, self.eval_epochs, self.eval_scores = [], [], []
         if mode == "predict":
@@ -84,6 +85,7 @@ class RecommenderALS:
         if Utrain.nnz and Utrain.data.min() < 0:
             raise ValueError("ratings must be >= 0 (implicit confidence c = 1 + alpha r)")
         self.Utrain = Utrain
+        self._exclusions = None
         self.Utest = None if Utest is None else sps.csr_matrix(Utest)
         if self.Utest is not None:
             self.Utest.sort_indices()
@@ -205,7 +207,15 @@ class RecommenderALS:
         read: 200).  filter_rated drops items the user rated in the training data
         (RecommenderService.py:16-29)."""
         k = min(int(k), self.n_items)
-        ex = (self.Utrain.indptr.astype(np.int64), self.Utrain.indices) if (filter_rated and self.Utrain is not None) else None
+        ex = None
+        if filter_rated and self.Utrain is not None:
+            # the training matrix as the engine already holds it on the device; otherwise uploaded once and kept
+            if self.engine is not None:
+                ex = self.engine.csr_users
+            else:
+                if self._exclusions is None:
+                    self._exclusions = ops.device_exclusions((self.Utrain.indptr, self.Utrain.indices), self.device)
+                ex = self._exclusions
         if ex is not None:
             u = np.asarray(users, dtype=np.int64).reshape(-1)
             if u.size and (u.min() < 0 or u.max() >= self.Utrain.shape[0]):

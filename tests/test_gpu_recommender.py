@@ -172,6 +172,83 @@ def test_update_user_foldin(ra, golden):
     assert np.abs(X[0] - ref[0]).max() / np.abs(ref[0]).max() < 1e-4
 
 
+def test_phantom_rows_enter_the_gram_like_the_tf_path(ra):
+    """The TensorFlow path sizes its embedding layers N + 1 / M + 1 (ALS.py:456): the extra row is never updated
+    but its random initial value is part of Y^T Y (ALS.py:243).  phantom_rows=1 reproduces that layout.  One
+    iteration with a NON-ZERO phantom row against the float32 restatement of the padded-batch TF path
+    (als_ref.half_sweep_batched_f32, ALS.py:160-233) and against the exact float64 solve with the phantom row in
+    the Gram; the phantom rows stay untouched, and leaving them out of the Gram changes the factors."""
+    rng = np.random.default_rng(31)
+    N, M, f, lamb, alpha = 300, 200, 20, 0.01, 40.0
+    U = sps.random(N, M, density=0.08, random_state=7, data_rvs=lambda n: rng.integers(1, 6, size=n).astype(np.float64)).tocsr()
+    U.sort_indices()
+    Ut = sps.csr_matrix(U.T); Ut.sort_indices()
+    rec = ra.RecommenderALS(mode="train", n_users=N, n_items=M,
+                            als_kwargs={"f": f, "lamb": lamb, "alpha": alpha, "epochs": 1, "phantom_rows": 1, "init": "tf"})
+    rec.input_data(U)
+    rec._ensure_factors()
+    X0 = rec.X.cpu().numpy().copy(); Y0 = rec.Y.cpu().numpy().copy()
+    assert X0.shape == (N + 1, f) and Y0.shape == (M + 1, f)
+    assert np.abs(Y0[M]).max() > 0 and np.abs(X0[N]).max() > 0          # the phantom rows are not zero
+    rec.train(evaluate=False)
+    X, Y = rec.X.cpu().numpy(), rec.Y.cpu().numpy()
+    assert np.array_equal(X[N], X0[N]) and np.array_equal(Y[M], Y0[M])  # never updated
+    # float32 restatement of the TF path: users against the item layer, then items against the new user layer
+    Xb, _ = als_ref.half_sweep_batched_f32(U.indptr, U.indices, U.data, M, Y0, X0, lamb, alpha)
+    Yb, _ = als_ref.half_sweep_batched_f32(Ut.indptr, Ut.indices, Ut.data, N, Xb, Y0, lamb, alpha)
+    # exact float64 solve; its Gram runs over every row of the layer handed in, phantom row included
+    Xe = als_ref.half_sweep_exact(U.indptr, U.indices, U.data, Y0.astype(np.float64), X0[:N].astype(np.float64), lamb, alpha)
+    Xl = np.vstack([Xe, X0[N:].astype(np.float64)])
+    Ye = als_ref.half_sweep_exact(Ut.indptr, Ut.indices, Ut.data, Xl, Y0[:M].astype(np.float64), lamb, alpha)
+
+    def rel(a, b):
+        return np.abs(a - b).max() / np.abs(b).max()
+    assert rel(X[:N], Xe) < 1e-4 and rel(Y[:M], Ye) < 1e-4
+    # the float32 path inverts in float32 (np.linalg.inv, ALS.py:172): its own distance to the exact solve bounds ours to it
+    assert rel(X[:N], Xb[:N]) < max(2e-3, 2 * rel(Xb[:N], Xe)) and rel(Y[:M], Yb[:M]) < max(2e-3, 2 * rel(Yb[:M], Ye))
+    # without the phantom row in the Gram the result is another one
+    Xn = als_ref.half_sweep_exact(U.indptr, U.indices, U.data, Y0[:M].astype(np.float64), X0[:N].astype(np.float64), lamb, alpha)
+    assert rel(Xn, Xe) > 1e-3
+
+
+def test_facade_names_and_refresh_gram(ra, golden):
+    """The names of the reference's Environment facade (Environment.py:14-45): fit = train, similar(items) = cosine
+    neighbours over the item factors (RecAlgos.py:61-73), make_update_data packs (rows, cols, vals) for update_user
+    (ALS.py:356-373); update_user(refresh_gram=False) reuses the Gram of the last fold-in as ALS.py:375-385 reuses
+    the one of the last epoch, refresh_gram=True recomputes it from the current item factors."""
+    g, U = _g2(golden)
+    N, M = U.shape
+    rec = ra.RecommenderALS(mode="train", n_users=N, n_items=M, als_kwargs={"f": 20, "lamb": 0.01, "alpha": 40.0, "epochs": 2})
+    rec.input_data(U)
+    rec.fit()
+    assert rec.X is not None and len(rec.trace) == 2
+    items = np.array([0, 5, 17])
+    idx, sims = rec.similar(items)
+    oidx, osims = als_ref.cosine_similar(rec.Y.cpu().numpy().astype(np.float64), items, M)
+    assert idx.shape[0] == len(items) and np.allclose(np.asarray(sims)[:, 0], 1.0, atol=1e-5)        # an item is its own nearest
+    k = min(10, np.asarray(idx).shape[1])
+    assert np.array_equal(np.asarray(idx)[:, :k], oidx[:, :k])
+    assert np.allclose(np.asarray(sims)[:, :k], osims[:, :k], atol=1e-5)
+    r, c, v = sps.find(U[3])
+    upd = rec.make_update_data((np.full_like(r, 3), c, v))
+    assert rec.make_update_data((np.zeros(0), np.zeros(0), np.zeros(0))) == []           # ALS.py:390
+    rec.update_user(upd, refresh_gram=True)
+    fresh = rec.X[3].clone()
+    one = sps.csr_matrix(U[3])
+    Yc = rec.Y.cpu().numpy().astype(np.float64)
+    ref = als_ref.half_sweep_exact(one.indptr, one.indices, one.data, Yc, np.zeros((1, 20)), 0.01, 40.0)
+    assert np.abs(fresh.cpu().numpy() - ref[0]).max() / np.abs(ref[0]).max() < 1e-4
+    # refresh_gram=False: the Gram the last epoch left behind, taken BEFORE its item sweep (ALS.py:345-349)
+    rec.update_user(upd, refresh_gram=False)
+    stale = rec.X[3].clone()
+    assert not torch.equal(stale, fresh)
+    Xt = rec.X.clone()
+    ra.half_sweep(upd, rec.Y, rec.engine.cache_Y, Xt, 40.0)
+    assert torch.equal(Xt[3], stale)
+    rec.update_user(np.full_like(r, 3), c, v)                                            # the triplet form, refreshed
+    assert torch.equal(rec.X[3], fresh)
+
+
 def test_evaluate_matches_oracle_map(ra):
     """MAP@200 on a block-structured matrix (ExplicitDataDummy-like): same value as the oracle's
     evaluation of the oracle's factors to 3 decimals, and > 0.9 as tests/core/test_ALS.py:85-86."""
@@ -312,6 +389,38 @@ def test_c1_cg_training_metrics_to_three_decimals(ra, cg_steps):
     assert abs(score - oscore) < 5e-4, (score, oscore)
     assert abs(pg - po) < 5e-4, (pg, po)
     assert abs(rg - ro) < 5e-4, (rg, ro)
+
+
+def test_exclusions_indexed_by_user_id_on_the_device(ra):
+    """The "drop rated items" filter (RecommenderService.py:16-29) from the training CSR as it lies on the device:
+    the kernels read row user_ids[u] of it, for any block of users in any order - the same ranking as from host
+    arrays, as from the two-call path, and as from a CSR cut to the block by hand."""
+    rng = np.random.default_rng(44)
+    N, M, f, k = 700, 40000, 64, 50
+    X = torch.from_numpy(rng.normal(size=(N, f)).astype(np.float32)).cuda()
+    Y = torch.from_numpy(rng.normal(size=(M, f)).astype(np.float32)).cuda()
+    rows = [np.sort(rng.choice(M, size=int(c), replace=False)).astype(np.int32) for c in rng.integers(0, 300, size=N)]
+    rows[5] = np.zeros(0, np.int32)
+    ptr = np.zeros(N + 1, dtype=np.int64); np.cumsum([len(r) for r in rows], out=ptr[1:])
+    col = np.concatenate(rows)
+    users = torch.from_numpy(rng.permutation(N)[:333].astype(np.int64)).cuda()
+    dev = (torch.from_numpy(ptr).cuda(), torch.from_numpy(col).cuda())
+    i0, v0 = ra.ops.recommend_topk(X, Y, users, k, exclude_csr=(ptr, col), block_users=128)        # host arrays
+    i1, v1 = ra.ops.recommend_topk(X, Y, users, k, exclude_csr=dev, block_users=100)               # device tensors
+    i2, v2 = ra.ops.recommend_topk(X, Y, users, k, exclude_csr=dev, fused=False)                   # two-call path
+    assert torch.equal(i0, i1) and torch.equal(v0, v1) and torch.equal(i0, i2) and torch.equal(v0, v2)
+    uh = users.cpu().numpy()
+    for j in range(0, len(uh), 7):
+        assert not np.intersect1d(i0[j].cpu().numpy(), rows[uh[j]]).size
+    # the block CSR built by hand (row j = the exclusions of users[j]) through topk_rows gives the same
+    S = ra.scores(X, Y, users)
+    bp = np.zeros(len(uh) + 1, dtype=np.int64); np.cumsum([len(rows[u]) for u in uh], out=bp[1:])
+    bc = np.concatenate([rows[u] for u in uh])
+    i3, v3 = ra.topk_rows(S.clone(), k, (torch.from_numpy(bp).cuda(), torch.from_numpy(bc).cuda()))
+    i4, v4 = ra.topk_rows(S.clone(), k, dev, users)
+    assert torch.equal(i3, i0) and torch.equal(i4, i0) and torch.equal(v3, v0) and torch.equal(v4, v0)
+    with pytest.raises(ValueError):
+        ra.ops.recommend_topk(X, Y, users, k, exclude_csr=(ptr[:300], col))        # a user id beyond the CSR
 
 
 def _two_call(ra, X, Y, users, k, ex):

@@ -146,3 +146,36 @@ def test_csv_ingest_matches_reference_normalisation(tmp_path):
     tr2, te2 = d2.make_training_datasets(dtype="sparse")
     assert (d2.N, d2.M) == (6, 8) and (tr2 != tr).nnz == 0 and (te2 != te).nnz == 0
     assert np.array_equal(d2.user_keys, [3, 4, 17, 42, 99, 1000])
+
+
+def test_every_stream_lookup_sits_inside_a_device_guard():
+    """The library is handed torch's CURRENT stream of the CURRENT device; an operator whose tensors live on another
+    device must therefore look the stream up inside `with torch.cuda.device(<that tensor's device>)`, or its kernels
+    run on device 0's stream with another device's pointers.  Checked on the source: every `_stream()` call in
+    recommender_amd/ops.py has such a `with` among its ancestors."""
+    import ast
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "recommender_amd", "ops.py")
+    tree = ast.parse(open(path).read())
+    parents = {}
+    for node in ast.walk(tree):
+        for child in ast.iter_child_nodes(node):
+            parents[child] = node
+
+    def is_guard(w):
+        for item in w.items:
+            c = item.context_expr
+            if isinstance(c, ast.Call) and ast.unparse(c.func) == "torch.cuda.device":
+                return True
+        return False
+
+    calls = [n for n in ast.walk(tree) if isinstance(n, ast.Call) and isinstance(n.func, ast.Name) and n.func.id == "_stream"]
+    assert len(calls) >= 8          # gram x3, the sweeps, scoring, top-k ...
+    for call in calls:
+        node, guarded = call, False
+        while node in parents:
+            node = parents[node]
+            if isinstance(node, ast.With) and is_guard(node):
+                guarded = True
+                break
+        assert guarded, "ops.py:%d: _stream() outside `with torch.cuda.device(...)`" % call.lineno
