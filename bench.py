@@ -356,6 +356,8 @@ def main():
                              "nnz_per_s": r["value"], "ms_per_step": r["ms_per_step"], "launch_ms": r["launch_ms"],
                              "achieved_GBs": r["achieved"], "frac": r["achieved"] / HBM_PEAK_GBS,
                              "algorithmic_bytes_per_launch": r["bytes_per_launch"], "kernel": r["kernel"],
+                             "traffic": pmc_traffic("%s_f%d%s" % (wname, r["f"], "" if solver != "cg" else
+                                                                  "_cg" if cgs == args.cg_steps else "_cg%d" % cgs)),
                              "rows_this_rank": {"user": r["user_rows"], "item": r["item_rows"]}})
             except Exception as exc:            # a failing extra point must not cost the headline line
                 also.append({"workload": wname, "f": ff, "solver": solver, "cg_steps": cgs or None, "error": repr(exc)})

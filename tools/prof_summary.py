@@ -8,7 +8,8 @@ out = sys.argv[1]
 
 def short(name):
     n = name
-    for k in ("sweep_items_kernel", "sweep_long_rows_kernel", "gram_chunk_kernel", "gram_finalize_kernel",
+    for k in ("sweep_stream_kernel", "scores_split_kernel", "topk_rows_kernel", "select_candidates_kernel", "wide_row_items_kernel",
+              "sweep_items_kernel", "sweep_long_rows_kernel", "gram_chunk_kernel", "gram_finalize_kernel",
               "sum_groups_kernel", "sum_to_double_kernel", "cg_items_kernel", "cg_long_rows_kernel", "scores_kernel",
               "gram_wide_chunk_kernel", "sum_slots_kernel"):
         if k in n:
@@ -43,24 +44,33 @@ for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
         print("  " + k + "  " + "  ".join("%s=%.4g" % (c, sum(v) / len(v)) for c, v in sorted(agg[k].items())) +
               "  (n=%d)" % len(next(iter(agg[k].values()))))
 
-# HBM traffic of the dominant kernel per launch, for bench.py's roofline.traffic.  FETCH_SIZE and
-# WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes for 16-byte-per-lane
-# loads (the sweep's gathers), so the read side is doubled; WRITE_SIZE is exact.
+# HBM traffic of one half-sweep's per-row kernels, for bench.py's roofline.traffic: every kernel between the taps runs
+# once per half-sweep, so the per-launch figure is the sum over them of the per-dispatch average.  FETCH_SIZE and
+# WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies the 128-byte requests of 16-byte-per-lane loads (global_load and
+# LDS-DMA alike - the sweep's gathers) at 64 bytes, so the read side is doubled; WRITE_SIZE is exact.  Infinity-Cache
+# hits are counted in, not excluded.
 import json
-fetch = write = None
+ROW_KERNELS = ("sweep_stream_kernel", "sweep_items_kernel", "sweep_long_rows_kernel", "sum_slots_kernel", "wide_row_items_kernel",
+               "cg_items_kernel", "cg_long_rows_kernel")
+fetch, write = {}, {}
 for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
     cc = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True) if os.path.isdir(d) else []
     for f in cc:
-        vals = collections.defaultdict(list)
+        vals = collections.defaultdict(lambda: collections.defaultdict(list))
         for row in csv.DictReader(open(f)):
-            if "sweep_items_kernel" in row["Kernel_Name"]:
-                vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
-        if "FETCH_SIZE" in vals: fetch = sum(vals["FETCH_SIZE"]) / len(vals["FETCH_SIZE"])
-        if "WRITE_SIZE" in vals: write = sum(vals["WRITE_SIZE"]) / len(vals["WRITE_SIZE"])
-if fetch is not None and write is not None:
-    t = {"kernel": "sweep_items_kernel", "FETCH_SIZE_KiB_avg": fetch, "WRITE_SIZE_KiB_avg": write,
-         "hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024,
-         "note": "average over the user-sweep and item-sweep launches; read side = FETCH_SIZE x 2 (gfx950 correction)"}
+            k = short(row["Kernel_Name"])
+            if k in ROW_KERNELS:
+                vals[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        for k, v in vals.items():
+            if "FETCH_SIZE" in v: fetch[k] = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"])
+            if "WRITE_SIZE" in v: write[k] = sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
+if fetch and write:
+    ft, wt = sum(fetch.values()), sum(write.values())
+    t = {"kernels": sorted(fetch), "FETCH_SIZE_KiB_avg": ft, "WRITE_SIZE_KiB_avg": wt,
+         "FETCH_SIZE_KiB_by_kernel": fetch, "WRITE_SIZE_KiB_by_kernel": write,
+         "hbm_bytes_per_launch": ft * 1024 * 2 + wt * 1024,
+         "note": "sum over the per-row kernels of a half-sweep of their per-dispatch averages (user and item sweeps averaged); "
+                 "read side = FETCH_SIZE x 2 (gfx950 correction)"}
     json.dump(t, open(os.path.join(out, "pmc_traffic_entry.json"), "w"), indent=1)
-    print("== HBM traffic per sweep launch: %.3f GB (fetch x2 %.3f GB + write %.3f GB)" %
-          (t["hbm_bytes_per_launch"] / 1e9, fetch * 2048 / 1e9, write * 1024 / 1e9))
+    print("== HBM traffic per half-sweep (%s): %.3f GB (fetch x2 %.3f GB + write %.3f GB)" %
+          (", ".join(sorted(fetch)), t["hbm_bytes_per_launch"] / 1e9, ft * 2048 / 1e9, wt * 1024 / 1e9))
