@@ -99,18 +99,23 @@ def _host_staged(T, group):
 
 
 _PADDED_RECV = {}      # (device, dtype, world, cap, trailing shape) -> receive buffer of the padded fallback, allocated once
-_UNEVEN_LIST_OK = [True]   # False once the backend has refused an all_gather with outputs of different sizes
+# Blocks of different sizes over RCCL: "padded" (default) = one all_gather_into_tensor through the persistent padded
+# buffer, the collective every RCCL build runs; "list" = all_gather into T's own row-block views (torch turns it into one
+# broadcast per rank inside one RCCL group: no staging pass, but a path that has not run on more than one GPU here).
+import os as _os
+_UNEVEN_LIST_OK = [_os.environ.get("ALS_ALLGATHERV", "padded") == "list"]
 
 
 def _all_gather_row_blocks(T, starts, sizes, rank, group):
     """All-gather of one row block per rank of the replicated T, in place: rank r owns
-    T[starts[r] : starts[r] + sizes[r]] and every rank ends up with all of them.  No padded staging:
+    T[starts[r] : starts[r] + sizes[r]] and every rank ends up with all of them:
 
       * RCCL, equal blocks that tile T: all_gather_into_tensor straight into T;
-      * RCCL otherwise: all_gather into the list of T's own row-block views.  For blocks of different sizes torch
-        issues one broadcast per rank inside one RCCL group (every receive lands in place, nothing is staged or
-        padded).  Should a backend refuse the uneven form, the blocks travel padded through ONE receive buffer that
-        is allocated once and kept;
+      * RCCL, equal blocks elsewhere: all_gather into the list of T's own row-block views;
+      * RCCL, blocks of different sizes: padded to the longest through ONE receive buffer that is allocated once and
+        kept (one all_gather_into_tensor, then each block is copied to its place); with ALS_ALLGATHERV=list instead
+        all_gather into the views, which torch issues as one broadcast per rank inside one RCCL group (every receive
+        lands in place) - should the backend refuse that form, the padded one takes over;
       * other backends (gloo in tests): one broadcast per rank of host copies - they get host tensors (_host_staged)."""
     world = len(sizes)
     if max(sizes) == 0:

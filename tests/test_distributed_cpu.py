@@ -1,6 +1,6 @@
 """world_size > 1 on CPU (gloo): the engine's sharded run must reproduce the single-process run
-bit for bit - the user sweep in overlapped row chunks, equal row shards, unequal shards (one padded
-all-gather),
+bit for bit - the user sweep in overlapped row chunks, equal row shards, unequal shards (cut by stored
+entries; every rank's row block travels as it is, one broadcast per rank, nothing padded or staged),
 sharded Gram (fixed 65 536-row partials all-gathered and summed in row order) and the replicated
 Gram of a small factor.  The HIP operators are replaced by tests/oracle_backend.py."""
 import os
