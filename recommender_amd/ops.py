@@ -75,6 +75,7 @@ def sweep_opts(accumulate="default", row_kernel="auto", tap=None):
     o = _lib.SweepOpts(_lib.ACCUMULATE_MODES[accumulate], _lib.ROW_KERNELS[row_kernel], None, None)
     if tap is not None:
         o.tap_begin, o.tap_end = tap[0].cuda_event, tap[1].cuda_event
+        o._tap = tap            # keeps the events alive, and lets a call made of several library calls record them itself
     return o
 
 
@@ -387,10 +388,18 @@ def half_sweep_cg(csr, Yopp, gram_cache, Xown, alpha, cg_steps, absdiff=None, in
             and lib.als_half_sweep_cg_workspace_bytes(csr.shape[0], csr.n_slots, f) > LOCKSTEP_WS_LIMIT:
         slabs, ws = csr.lockstep_slabs(f, LOCKSTEP_WS_LIMIT)
         parts = torch.zeros(len(slabs), dtype=torch.float64, device=csr.device)
+        tap = getattr(opts, "_tap", None) if opts is not None else None
+        if tap is not None:         # the tap brackets all slabs, not the last one
+            opts = _lib.SweepOpts(opts.accumulate, opts.row_kernel, None, None)
+            with torch.cuda.device(csr.device):
+                tap[0].record(torch.cuda.current_stream())
         for k, (r0, r1, sub) in enumerate(slabs):
             Xs = Xown if sub.row_ids is not None else Xown[r0:r1]
             half_sweep_cg(sub, Yopp, gram_cache, Xs, alpha, cg_steps, absdiff=parts[k:k + 1], info=info, form=form,
                           opts=opts, _ws=ws)
+        if tap is not None:
+            with torch.cuda.device(csr.device):
+                tap[1].record(torch.cuda.current_stream())
         torch.sum(parts, 0, keepdim=True, out=absdiff)           # slab order: a fixed order
         return absdiff
     ws = csr.workspace_cg(f) if _ws is None else _ws

@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p "$ROOT/gpurun_out"
 run() {   # tag, bench args...
   local tag=$1; shift
-  timeout -k 10 600 python3 "$ROOT/bench.py" --no-cpu-baseline "$@" > "$ROOT/gpurun_out/repro_$tag.log" 2>&1 || { echo "$tag FAILED"; tail -5 "$ROOT/gpurun_out/repro_$tag.log"; return 1; }
+  timeout -k 10 600 python3 "$ROOT/bench.py" --no-cpu-baseline --no-also "$@" > "$ROOT/gpurun_out/repro_$tag.log" 2>&1 || { echo "$tag FAILED"; tail -5 "$ROOT/gpurun_out/repro_$tag.log"; return 1; }
   grep "^{" "$ROOT/gpurun_out/repro_$tag.log" > "$ROOT/gpurun_out/repro_$tag.json"
   python3 - "$tag" "$ROOT/gpurun_out/repro_$tag.json" <<'PY'
 import json, sys
@@ -18,13 +18,22 @@ PY
 }
 run c2_f64_exact                                   && \
 run c2_f64_exact_fp32    --accumulate fp32         && \
-run c2_f64_cg            --solver cg               && \
+run c2_f64_cg10          --solver cg               && \
+run c2_f64_cg3           --solver cg --cg-steps 3  && \
 run c2_f128_exact        --factors 128 --steps 5   && \
 run c2_f128_exact_fp32   --factors 128 --steps 5 --accumulate fp32 && \
-run c2_f128_cg           --factors 128 --steps 5 --solver cg && \
-run c2_f128_cg_lockstep  --factors 128 --steps 5 --solver cg --cg-form lock_step && \
-run c2_f256_cg           --factors 256 --steps 5 --solver cg && \
+run c2_f128_exact_wave   --factors 128 --steps 5 --row-kernel wave && \
+run c2_f128_cg10         --factors 128 --steps 5 --solver cg && \
+run c2_f128_cg3          --factors 128 --steps 5 --solver cg --cg-steps 3 && \
+run c2_f128_cg3_lockstep --factors 128 --steps 5 --solver cg --cg-steps 3 --cg-form lock_step && \
+run c2_f256_cg10         --factors 256 --steps 5 --solver cg && \
+run c2_f256_cg3          --factors 256 --steps 5 --solver cg --cg-steps 3 && \
 run c3shard_exact        --workload c3_shard_syn --steps 3 --warmup 1 && \
-run c3shard_cg           --workload c3_shard_syn --steps 3 --warmup 1 --solver cg && \
-run c4shard_cg           --workload c4_shard_syn --steps 2 --warmup 1 && \
-python3 "$ROOT/tools/bench_topk.py" && python3 "$ROOT/tools/bench_gram.py"
+run c3shard_exact_wave   --workload c3_shard_syn --steps 3 --warmup 1 --row-kernel wave && \
+run c3shard_cg10         --workload c3_shard_syn --steps 3 --warmup 1 --solver cg && \
+run c3shard_cg3          --workload c3_shard_syn --steps 3 --warmup 1 --solver cg --cg-steps 3 && \
+run c3shard_cg3_wave     --workload c3_shard_syn --steps 3 --warmup 1 --solver cg --cg-steps 3 --row-kernel wave && \
+run c4shard_cg10         --workload c4_shard_syn --steps 2 --warmup 1 && \
+run c4shard_cg3          --workload c4_shard_syn --steps 2 --warmup 1 --cg-steps 3 && \
+python3 "$ROOT/tools/bench_topk.py" --users 65536 --skip-materialised && \
+python3 "$ROOT/tools/bench_topk.py" --users 1048576 --filter-rated --skip-materialised && python3 "$ROOT/tools/bench_gram.py"
