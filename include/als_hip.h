@@ -4,7 +4,7 @@
  * The reference (whong92/recommender, package reclibwh) has no native interface: its
  * boundary for this path is a set of Python functions in reclibwh/core/ALS.py.  Every
  * entry point below names the reference function it stands in for.  A host binds these
- * with ctypes (see INTEGRATION.md); signatures use plain pointers and sizes only.
+ * with ctypes; signatures use plain pointers and sizes only.
  *
  * Conventions
  *   - every pointer marked [device] is device memory owned by the caller; the library

@@ -83,7 +83,7 @@ def to_scipy(csr, shape):
     return sps.csr_matrix((val.astype(np.float64), col, rowptr), shape=shape)
 
 
-# Named workloads (BASELINE.json configs; dimensions are the GroupLens ones)
+# Named workloads (the benchmark configurations; dimensions are the GroupLens ones)
 WORKLOADS = {
     # ml-latest-small shaped: 610 x 9724, 80 668 training ratings, f=20, 15 iterations
     "c1_ml_small_syn": dict(n_users=610, n_items=9724, nnz=80668, f=20, lamb=0.01, alpha=40.0, iters=15),

@@ -226,7 +226,7 @@ def test_accumulate_modes_agree_and_both_hold_parity(ra, f):
 
 
 def test_integration_stub_from_the_docs_runs(ra):
-    """The ctypes binding printed in INTEGRATION.md (operator level: plan, Gram cache, half-sweep),
+    """The ctypes binding printed in the integration guide at the repository root (operator level: plan, Gram cache, half-sweep),
     executed as printed, reproduces the oracle's half-sweep."""
     import os
     import re

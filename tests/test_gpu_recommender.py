@@ -277,7 +277,7 @@ def test_evaluate_matches_oracle_map(ra):
 
 
 def test_c1_full_training_metrics_to_three_decimals(ra):
-    """BASELINE configs[0] at its own size (ml-latest-small shaped synthetic: 610 x 9 724,
+    """The smallest benchmark configuration at its own size (ml-latest-small shaped synthetic: 610 x 9 724,
     100 836 ratings split 80/20, f=20, 15 iterations, alpha=40, lamb=0.01 as ALS.py:457):
     RecommenderALS.train() against the float64 oracle run from the same seed-42 init.
     Bars: factors 1e-4 relative after the 15th iteration; MAP@200 (the reference's eval.csv
@@ -355,7 +355,7 @@ CG_STEPS_DEFAULT = 10
 
 @pytest.mark.parametrize("cg_steps", [CG_STEPS_DEFAULT, 2 * CG_STEPS_DEFAULT])
 def test_c1_cg_training_metrics_to_three_decimals(ra, cg_steps):
-    """The conjugate-gradient solver at metric level, on BASELINE configs[0] at its own size: 15 iterations with
+    """The conjugate-gradient solver at metric level, on the smallest benchmark configuration at its own size: 15 iterations with
     `cg_steps` warm-started steps per row (10 is the default of RecommenderALS and of the benchmark's CG lines;
     3 steps miss MAP@200 by 5e-3 and 6 by 2e-3 here, 8 miss precision@10 by 6e-4)
     against the EXACT float64 solve of reclibwh/core/ALS.py:82-86 run from the same init.  The truncated iteration

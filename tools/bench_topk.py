@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Serving-path benchmark (BASELINE configs[4]): top-100 items for a block of users against
+"""Serving-path benchmark (the 10 M-user top-100 serving configuration): top-100 items for a block of users against
 1 M items from f=128 factors, all resident.  Reports users/s and the split between the score
 kernel alone writing every score (bf16-split products on the matrix cores; store bound) and the fused
 path, which never stores them.  --filter-rated: every user's training items (a synthetic CSR with --avg-rated

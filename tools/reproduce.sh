@@ -1,5 +1,5 @@
 #!/bin/bash
-# Re-measures every row of the table in DESIGN.md section 6 on one MI355X (a few minutes in total).
+# Re-measures every configuration of the project's measurement table on one MI355X (a few minutes in total).
 # usage: tools/reproduce.sh            results: gpurun_out/repro_<tag>.json, one bench.py line each
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
