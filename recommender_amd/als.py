@@ -98,7 +98,7 @@ def _host_staged(T, group):
     return T.is_cuda and torch.distributed.get_backend(group) != "nccl"
 
 
-_PADDED_RECV = {}      # (device, dtype, world, cap, trailing shape) -> receive buffer of the padded fallback, allocated once
+_PADDED_RECV = {}      # (device, dtype, world, cap, trailing shape) -> (receive, send) buffers of the padded form, allocated once
 # Blocks of different sizes over RCCL: "padded" (default) = one all_gather_into_tensor through the persistent padded
 # buffer, the collective every RCCL build runs; "list" = all_gather into T's own row-block views (torch turns it into one
 # broadcast per rank inside one RCCL group: no staging pass, but a path that has not run on more than one GPU here).
@@ -148,17 +148,26 @@ def _all_gather_row_blocks(T, starts, sizes, rank, group):
             if equal:
                 raise
             _UNEVEN_LIST_OK[0] = False      # the same on every rank: the sizes are checked before anything is sent
+    _all_gather_padded(T, starts, sizes, rank, group)
+
+
+def _all_gather_padded(T, starts, sizes, rank, group):
+    """Row blocks of different sizes, padded to the longest: ONE all_gather_into_tensor through a receive and a send
+    buffer that are allocated once per (device, dtype, world, longest block, row shape) and kept; then every other
+    rank's block is copied to its place in T."""
+    world = len(sizes)
     cap = max(sizes)
     key = (T.device, T.dtype, world, cap, tuple(T.shape[1:]))
-    recv = _PADDED_RECV.get(key)
-    if recv is None:
-        recv = _PADDED_RECV[key] = torch.empty((world, cap) + tuple(T.shape[1:]), dtype=T.dtype, device=T.device)
-    send = recv[rank]
-    send[: sizes[rank]] = mine
+    bufs = _PADDED_RECV.get(key)
+    if bufs is None:        # a send buffer of its own: no reliance on in-place collectives
+        bufs = _PADDED_RECV[key] = (torch.empty((world, cap) + tuple(T.shape[1:]), dtype=T.dtype, device=T.device),
+                                    torch.zeros((cap,) + tuple(T.shape[1:]), dtype=T.dtype, device=T.device))
+    recv, send = bufs
+    send[: sizes[rank]] = T[starts[rank]: starts[rank] + sizes[rank]]
     torch.distributed.all_gather_into_tensor(recv.view((world * cap,) + tuple(T.shape[1:])), send, group=group)
     for r in range(world):
         if r != rank and sizes[r]:
-            views[r].copy_(recv[r, : sizes[r]])
+            T[starts[r]: starts[r] + sizes[r]].copy_(recv[r, : sizes[r]])
 
 
 def _all_gather_rows(T, bounds, rank, group):
