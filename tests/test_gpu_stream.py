@@ -61,6 +61,47 @@ def test_stream_equals_wave_and_oracle(f, shape):
         assert out[("stream", cg)][1] == out[("wave", cg)][1]
 
 
+def test_stream_block_boundaries_padded_rows_and_row_ids():
+    """Row lengths at the 32-entry block boundaries (0, 1, 31, 32, 33, 63, 64, 65, ...), a matrix without any entry,
+    factor tables with a padded leading dimension, and rows written through row_ids (the fold-in's mapping): the
+    stream kernel returns the one-wave kernel's bits every time."""
+    import recommender_amd as ra
+
+    rng = np.random.default_rng(77)
+    f, M, ld = 128, 900, 160
+    lens = np.array([0, 1, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 0, 0, 200, 2, 32, 64] * 60, dtype=np.int64)
+    N = len(lens)
+    ptr = np.zeros(N + 1, dtype=np.int64)
+    np.cumsum(lens, out=ptr[1:])
+    ind = np.concatenate([np.sort(rng.choice(M, size=l, replace=False)) for l in lens]).astype(np.int32)
+    dat = (rng.integers(0, 11, size=ptr[-1]) * 0.5).astype(np.float32)          # stored zeros included
+    Ys = torch.from_numpy(rng.normal(0, 0.1, size=(M, ld)).astype(np.float32)).cuda()
+    Y = Ys[:, :f]
+    gc = ra.gram(Y, 0.01)
+    X0 = rng.normal(0, 0.1, size=(3 * N, ld)).astype(np.float32)
+    row_ids = rng.permutation(3 * N)[:N].astype(np.int64)
+    cases = {
+        "plain": ra.DeviceCSR(ptr, ind, dat, (N, M), "cuda"),
+        "row_ids": ra.DeviceCSR(ptr, ind, dat, (N, M), "cuda", row_ids=row_ids),
+        "empty": ra.DeviceCSR(np.zeros(N + 1, dtype=np.int64), np.zeros(0, np.int32), np.zeros(0, np.float32), (N, M), "cuda"),
+    }
+    for name, csr in cases.items():
+        for cg in (0, 3):
+            got = {}
+            for rk in ("wave", "stream"):
+                X = torch.from_numpy(X0).cuda()[:, :f]
+                o = ra.ops.sweep_opts(row_kernel=rk)
+                if cg:
+                    d = ra.ops.half_sweep_cg(csr, Y, gc, X, 40.0, cg, form="matrix", opts=o)
+                else:
+                    d = ra.half_sweep(csr, Y, gc, X, 40.0, opts=o)
+                got[rk] = (X.cpu().numpy(), float(d.item()))
+            assert np.array_equal(got["wave"][0], got["stream"][0]), (name, cg)
+            assert got["wave"][1] == got["stream"][1], (name, cg)
+            if name == "empty":
+                assert not got["stream"][0][:N].any()
+
+
 def test_stream_rejects_what_it_cannot_run():
     import recommender_amd as ra
 
