@@ -203,6 +203,16 @@ __device__ __forceinline__ f32x4 mfma_bf16(const u32x4 &a, const u32x4 &b, const
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // m0 is reserved, and written here on purpose: the LDS address of the DMA
+// 64 lanes x 16 bytes from g (per lane) to LDS bytes [lds, lds + 1024), lane l at 16 l
+__device__ __forceinline__ void score_dma16(const void *g, const unsigned lds) {
+    // (the address is wave uniform; readfirstlane makes the compiler keep it in a scalar register where it cannot tell)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(g), "s"(__builtin_amdgcn_readfirstlane((int)lds)) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
 constexpr int SB_USERS = 128;   // users per workgroup
 constexpr int SB_ITEMS = 32;    // items per stage
 
@@ -249,13 +259,20 @@ __global__ __launch_bounds__(256, 2) void scores_split_kernel(const float *__res
                 tau[a][r] = cand.score[min(u0 + 16 * a + 4 * g + r, nu - 1) * cand.cap + cand.k - 1];
     }
 
-    // issue: raw loads only (from offset 0 where the segment lies beyond f), so nothing waits for them
-    // before the stage's matrix work; commit zeroes what lies beyond f, splits and writes to LDS
-    // loads run two stages ahead of the matrix work (a stage lasts about a microsecond, less than a
-    // trip to HBM under load): a register set is refilled as soon as its rows have gone to LDS
-    f32x4 ya[2][NP], yb[2][NP];
+    // The item rows travel global -> LDS by LDS-DMA (no destination registers) into a per-thread parking area (`raw`:
+    // a thread later reads back exactly the 16-byte pieces its own lane loaded), two stages ahead of the matrix work.
+    // The DMA is inline assembly and its wait an explicit count: left to the compiler, the conditional atomics and
+    // stores of the FILTER epilogue (they share the vector-memory counter) make it drain every load before the
+    // epilogue ends - a prefetch one stage deep whatever the source says - and a known LDS-DMA makes it drain the
+    // counter before every LDS read.  Unknown to it, the loads of stage t + 2 stay in flight through all of stage
+    // t + 1.  Operations issued behind a load (the epilogue's) only make the counted wait stricter, never wrong.
+    // Every stage issues and commits, also past the range's end (rows clamp to the last item, their fragments go to
+    // the LDS buffer nobody reads): one fixed shape.
+    __shared__ f32x4 raw[2][2 * NP][256];
+    const unsigned raw_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) f32x4 *)&raw[0][0][0] + wave * 1024;
     auto issue = [&](auto set_c, const int64_t t) {
         constexpr int set = decltype(set_c)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // commit's reads of this set have returned
 #pragma unroll
         for (int n = 0; n < NP; ++n) {
             const int p = tid + 256 * n;               // wave uniform validity: PAIRS is a multiple of 64
@@ -263,20 +280,28 @@ __global__ __launch_bounds__(256, 2) void scores_split_kernel(const float *__res
                 const int c = p >> 6, it = c / KS, s = c % KS, k0 = 32 * s + 8 * g;
                 const int64_t item = min(item_begin + t * SB_ITEMS + it * 16 + j, M - 1);
                 const float *yrow = Y + item * ldy;
-                ya[set][n] = *reinterpret_cast<const f32x4 *>(yrow + (k0 < f ? k0 : 0));
-                yb[set][n] = *reinterpret_cast<const f32x4 *>(yrow + (k0 + 4 < f ? k0 + 4 : 0));
+                score_dma16(yrow + (k0 < f ? k0 : 0), raw_base + ((set * 2 * NP + 2 * n) * 256) * 16);
+                score_dma16(yrow + (k0 + 4 < f ? k0 + 4 : 0), raw_base + ((set * 2 * NP + 2 * n + 1) * 256) * 16);
             }
         }
     };
     auto commit = [&](auto set_c, const int buf) {
         constexpr int set = decltype(set_c)::value;
+        // behind this set's loads the wave issued the other set's: 2 per row segment it owns (wave uniform: the last
+        // segment index exists only for the first PAIRS - 256 (NP - 1) threads)
+        static_assert(NP == 1 || NP == 2, "wait counts below");
+        const bool all_segments = tid + 256 * (NP - 1) < PAIRS;
+        if (NP == 2 && all_segments) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if ((NP == 2) != all_segments) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int n = 0; n < NP; ++n) {
             const int p = tid + 256 * n;
             if (p < PAIRS) {
                 const int k0 = 32 * ((p >> 6) % KS) + 8 * g;
                 const f32x4 zero{0.f, 0.f, 0.f, 0.f};
-                const Frag3 fr = split8(k0 < f ? ya[set][n] : zero, k0 + 4 < f ? yb[set][n] : zero);
+                const f32x4 ya = raw[set][2 * n][tid], yb = raw[set][2 * n + 1][tid];
+                const Frag3 fr = split8(k0 < f ? ya : zero, k0 + 4 < f ? yb : zero);
                 u32x4 *dst = &stage[buf][(p >> 6) * 3 * 64 + lane];
                 dst[0] = fr.h; dst[64] = fr.m; dst[128] = fr.l;
             }
@@ -285,9 +310,9 @@ __global__ __launch_bounds__(256, 2) void scores_split_kernel(const float *__res
     using Set0 = std::integral_constant<int, 0>;
     using Set1 = std::integral_constant<int, 1>;
     issue(Set0{}, t0);
-    if (t0 + 1 < t1) issue(Set1{}, t0 + 1);
+    issue(Set1{}, t0 + 1);
     commit(Set0{}, 0);
-    if (t0 + 2 < t1) issue(Set0{}, t0 + 2);
+    issue(Set0{}, t0 + 2);
     __syncthreads();
     // FILTER: a hit reserves its slot in the user's candidate row with an integer atomic, whose answer
     // takes about as long as a stage.  The lane parks the hit and writes it after the next stage's
@@ -389,14 +414,15 @@ __global__ __launch_bounds__(256, 2) void scores_split_kernel(const float *__res
                     }
                 }
         }
-        if (t + 1 < t1) commit(Other{}, buf ^ 1);
-        if (t + 3 < t1) issue(Other{}, t + 3);       // into the registers commit has just read
+        commit(Other{}, buf ^ 1);
+        issue(Other{}, t + 3);                       // into the parking area commit has just read
         __syncthreads();
     };
     for (int64_t t = t0; t < t1; t += 2) {
         step(Set0{}, t);
         if (t + 1 < t1) step(Set1{}, t + 1);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // nothing of this wave is in flight towards its LDS when it ends
     if constexpr (FILTER) flush();
 }
 
