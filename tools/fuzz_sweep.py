@@ -38,6 +38,16 @@ for case in range(60):
     bar = max(1e-4, 3 * err32)
     flag = "" if (err < bar and int(info.item()) == 0) else "  <-- FAIL"
     worst = max(worst, err / bar)
+    if 64 < f <= 128 and f % 4 == 0 and ld % 4 == 0:       # the persistent stream kernel: the one-wave kernel's bits
+        for cg in (0, 3):
+            got = []
+            for rk in ("wave", "stream"):
+                Xs = torch.from_numpy(Xh).cuda()[:, :f]
+                o = ra.ops.sweep_opts(row_kernel=rk)
+                if cg: ra.ops.half_sweep_cg(csr, Y, gc, Xs, alpha, cg, form="matrix", opts=o)
+                else: ra.half_sweep(csr, Y, gc, Xs, alpha, opts=o)
+                got.append(Xs.cpu().numpy())
+            if not np.array_equal(got[0], got[1]): flag += "  <-- STREAM != WAVE (cg=%d)" % cg
     Xg = torch.from_numpy(Xh).cuda()[:, :f]
     ra.half_sweep_cg(csr, Y, gc, Xg, alpha, 3)
     refcg = als_ref.half_sweep_cg(ptr, ind, dat.astype(np.float64), Yh[:, :f].astype(np.float64), Xh[:, :f].astype(np.float64), lamb, alpha, 3)
