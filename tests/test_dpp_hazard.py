@@ -63,3 +63,13 @@ def test_checker_is_conservative_at_labels():
 def test_flags_come_from_the_makefile():
     flags = chk.makefile_flags()
     assert "-O3" in flags and "-fno-slp-vectorize" in flags
+
+
+def test_m0_lint_flags_compiler_uses():
+    """m0 may be written only by the `s_mov_b32 m0, <sgpr>` of the LDS-DMA assembly statements."""
+    lint = chk
+    ok = ";;#ASMSTART\n\ts_mov_b32 m0, s12\n\ts_nop 0\n\tglobal_load_lds_dwordx4 v[2:3], off\n;;#ASMEND\n"
+    assert lint.check_m0(ok) == []
+    assert len(lint.check_m0("\ts_mov_b32 m0, s12\n")) == 1                      # outside an assembly statement
+    assert len(lint.check_m0(";;#ASMSTART\n\ts_mov_b32 m0, v3\n;;#ASMEND\n")) == 1     # not from a scalar register
+    assert len(lint.check_m0("\tv_movrels_b32 v1, v2 ; uses m0\n\ts_movk_i32 m0, 0x3800\n")) == 1

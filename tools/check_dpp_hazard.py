@@ -117,6 +117,23 @@ def check(text):
     return bad
 
 
+def check_m0(text):
+    """The LDS-DMA of the stream and score kernels is issued from inline assembly that writes m0 (the DMA's LDS
+    address), a register reserved to the compiler, which is told so by a clobber it need not honour.  That is safe as
+    long as the compiler itself never keeps a value in m0 in these files: every instruction that names m0 must be the
+    `s_mov_b32 m0, <sgpr>` of such an assembly statement."""
+    bad, in_asm = [], False
+    for no, raw in enumerate(text.split("\n"), 1):
+        line = raw.strip()
+        if line.startswith(";;#ASMSTART"):
+            in_asm = True
+        elif line.startswith(";;#ASMEND"):
+            in_asm = False
+        elif re.search(r"\bm0\b", line.split(";")[0]) and not (in_asm and re.match(r"^s_mov_b32 m0, s\d+$", line.split(";")[0].strip())):
+            bad.append((no, line))
+    return bad
+
+
 def assembly_of(src):
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "k.s")
@@ -135,6 +152,9 @@ def main(argv):
         for kernel, no, ins, prev in check(text):
             total += 1
             print(f"{name}:{no}: {kernel[:60]}: `{ins}` reads a register written by `{prev}` too few wait states before")
+        for no, ins in check_m0(text):
+            total += 1
+            print(f"{name}:{no}: m0 used outside the LDS-DMA assembly statements: `{ins}`")
     print(f"{n_dpp} DPP instructions checked, {total} hazards")
     return 1 if total else 0
 
