@@ -527,17 +527,23 @@ __device__ __forceinline__ void diag_step(f32x4 &D, f32x4 &N, const int c) {
         N = f32x4{n0, n1, n2, n3};
     }
 }
-template <int... Ks>
-__device__ __forceinline__ void diag_steps(f32x4 &D, f32x4 &N, const int c, std::integer_sequence<int, Ks...>) {
-    (diag_step<Ks>(D, N, c), ...);
+struct NoFiller {
+    template <typename K> __device__ __forceinline__ void operator()(K) const {}
+};
+template <typename F, int... Ks>
+__device__ __forceinline__ void diag_steps(f32x4 &D, f32x4 &N, const int c, F &filler, std::integer_sequence<int, Ks...>) {
+    ((filler(std::integral_constant<int, Ks>{}), diag_step<Ks>(D, N, c)), ...);
 }
-// X = U_d^{-1} for the SPD tile D (U_d its upper Cholesky factor); ok = all pivots positive.
-__device__ __forceinline__ f32x4 diag_inverse_factor(f32x4 D, const int lane, bool &ok) {
+// X = U_d^{-1} for the SPD tile D (U_d its upper Cholesky factor); ok = all pivots positive.  filler(K) is called in
+// front of elimination step K: independent matrix-pipe work that is issued beside the step's chain of dependent
+// vector instructions.
+template <typename F = NoFiller>
+__device__ __forceinline__ f32x4 diag_inverse_factor(f32x4 D, const int lane, bool &ok, F filler = F{}) {
     const int g = lane >> 4, c = lane & 15;
     f32x4 N;
 #pragma unroll
     for (int r = 0; r < 4; ++r) N[r] = (4 * g + r == c) ? 1.f : 0.f;
-    diag_steps(D, N, c, std::make_integer_sequence<int, 16>{});
+    diag_steps(D, N, c, filler, std::make_integer_sequence<int, 16>{});
     // pivot d_c is still at lane (c>>2, c), register c&3 (column c is never touched after step c)
     const float lo = (c & 1) ? D[1] : D[0], hi = (c & 1) ? D[3] : D[2];
     const float dvec = __shfl((c & 2) ? hi : lo, 16 * (c >> 2) + c);
@@ -547,6 +553,30 @@ __device__ __forceinline__ f32x4 diag_inverse_factor(f32x4 D, const int lane, bo
 #pragma unroll
     for (int r = 0; r < 4; ++r) N[r] *= sc;
     return N;
+}
+
+// Back substitution on the factored tiles (diagonal slots hold X = U_kk^{-1}): the per-lane products of a block row
+// are added up first, one lane reduction per block.
+template <int VW>
+__device__ __forceinline__ void back_substitute(const f32x4 (&T)[Geo<VW>::NT], const float (&zcol)[VW], float (&x)[VW],
+                                                const int lane) {
+#ifdef ALS_ABLATE_NO_BACKSUB
+#pragma unroll
+    for (int kb = 0; kb < VW; ++kb) x[kb] = zcol[kb] + T[tile_index(kb, VW - 1, VW)][0];      // timing-only: wrong values
+    return;
+#endif
+#pragma unroll
+    for (int kb = VW - 1; kb >= 0; --kb) {
+        f32x4 part = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jb = kb + 1; jb < VW; ++jb) part += T[tile_index(kb, jb, VW)] * x[jb];
+        f32x4 acc = vec_col_to_row(zcol[kb], lane);
+        if (kb + 1 < VW) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] -= row_sum16(part[r]);
+        }
+        x[kb] = vec_row_to_col(tile_x_v(T[tile_index(kb, kb, VW)], vec_row_to_col(acc, lane)), lane);
+    }
 }
 
 // Solves T x = b.  T: the VW*(VW+1)/2 tiles (destroyed), b: column-indexed right-hand side per
@@ -563,12 +593,20 @@ __device__ __forceinline__ bool blocked_solve(f32x4 (&T)[Geo<VW>::NT], float (&b
 #pragma unroll
     for (int kb = 0; kb < VW; ++kb) {
         // the diagonal tile is dead once factored: its slot keeps X = U_kk^{-1} for the back substitution
+#ifdef ALS_ABLATE_NO_DIAG
+        const f32x4 X = T[tile_index(kb, kb, VW)];      // timing-only: wrong values
+#else
         const f32x4 X = diag_inverse_factor(T[tile_index(kb, kb, VW)], lane, ok);
+#endif
         T[tile_index(kb, kb, VW)] = X;
 #pragma unroll
         for (int jb = kb + 1; jb < VW; ++jb) {
             f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef ALS_ABLATE_NO_PANEL
+            u = X * T[tile_index(kb, jb, VW)];            // timing-only: wrong values
+#else
             tile_xtz<false>(X, T[tile_index(kb, jb, VW)], u);
+#endif
             T[tile_index(kb, jb, VW)] = u;
         }
         if (kb > 0) b[kb] -= grp_sum4(pend[kb]);
@@ -579,25 +617,150 @@ __device__ __forceinline__ bool blocked_solve(f32x4 (&T)[Geo<VW>::NT], float (&b
             const f32x4 Ui = T[tile_index(kb, ib, VW)];
             const f32x4 nUi = -Ui;
 #pragma unroll
-            for (int jb = ib; jb < VW; ++jb) tile_xtz<false>(nUi, T[tile_index(kb, jb, VW)], T[tile_index(ib, jb, VW)]);
+            for (int jb = ib; jb < VW; ++jb) {
+#ifdef ALS_ABLATE_NO_TRAILING
+                T[tile_index(ib, jb, VW)] += nUi * T[tile_index(kb, jb, VW)];   // timing-only: wrong values
+#else
+                tile_xtz<false>(nUi, T[tile_index(kb, jb, VW)], T[tile_index(ib, jb, VW)]);
+#endif
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) pend[ib] = fmaf(Ui[r], zrow[r], pend[ib]);
         }
         __builtin_amdgcn_sched_barrier(0);   // block steps stay in order: bounds the live ranges
     }
-    // back substitution: the per-lane products of a block row are added up first, one lane reduction per block
+    back_substitute<VW>(T, zcol, x, lane);
+    return ok;
+}
+
+// ----------------------------------------------------------------------------- blocked solve, block products on the bf16 pipe
+// The same right-looking block Cholesky with the panel solves U_kj = X^T A_kj and the trailing updates
+// A_ij -= U_ki^T U_kj as products of three-way bf16 splits (the accumulate's scheme: 6 of the 9 piece products,
+// float32 accumulation) on v_mfma_f32_16x16x16_bf16: 6 x 8 matrix-pipe cycles per tile product against 4 x 32 of the
+// float32 form - and, unlike the float32 form, running beside vector instructions.  A tile in accumulator layout is
+// again an operand as it lies: lane (g, c) holds rows 4g..4g+3 of column c, exactly the 4 k-slots a lane owns in the
+// A and in the B fragment (k = row).  The trailing products of block step k - 1 - all but the one into the next
+// diagonal tile - are issued in 16 portions in front of the 16 elimination steps of diagonal tile k, whose chain of
+// dependent vector instructions leaves the matrix pipe idle otherwise.
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+struct TilePieces { unsigned p[3][2]; };      // [0] hi, [1] mid, [2] lo; register q holds rows 4g + 2q, 4g + 2q + 1
+__device__ __forceinline__ TilePieces split_tile(const f32x4 &t) {
+    TilePieces o;
 #pragma unroll
-    for (int kb = VW - 1; kb >= 0; --kb) {
-        f32x4 part = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int jb = kb + 1; jb < VW; ++jb) part += T[tile_index(kb, jb, VW)] * x[jb];
-        f32x4 acc = vec_col_to_row(zcol[kb], lane);
-        if (kb + 1 < VW) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] -= row_sum16(part[r]);
-        }
-        x[kb] = vec_row_to_col(tile_x_v(T[tile_index(kb, kb, VW)], vec_row_to_col(acc, lane)), lane);
+    for (int q = 0; q < 2; ++q) {
+        const float x0 = t[2 * q], x1 = t[2 * q + 1];
+        const float r0 = x0 - trunc_bf16(x0), r1 = x1 - trunc_bf16(x1);
+        const float l0 = r0 - trunc_bf16(r0), l1 = r1 - trunc_bf16(r1);
+        o.p[0][q] = pack_trunc(x0, x1);
+        o.p[1][q] = pack_trunc(r0, r1);
+        o.p[2][q] = pack_trunc(l0, l1);
     }
+    return o;
+}
+__device__ __forceinline__ TilePieces negated(const TilePieces &a) {
+    TilePieces o;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) o.p[k][q] = a.p[k][q] ^ 0x80008000u;
+    return o;
+}
+__device__ __forceinline__ f32x4 mfma_bf16_k16(const unsigned (&a)[2], const unsigned (&b)[2], const f32x4 &c) {
+    const u32x2 av{a[0], a[1]}, bv{b[0], b[1]};
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf16x4, av), __builtin_bit_cast(bf16x4, bv), c, 0, 0, 0);
+}
+// piece product pr of out += X^T Z (smallest first: lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi)
+template <int PR>
+__device__ __forceinline__ void piece_product(const TilePieces &X, const TilePieces &Z, f32x4 &out) {
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    out = mfma_bf16_k16(X.p[PA[PR]], Z.p[PB[PR]], out);
+}
+__device__ __forceinline__ void tile_xtz_pieces(const TilePieces &X, const TilePieces &Z, f32x4 &out) {
+    piece_product<0>(X, Z, out); piece_product<1>(X, Z, out); piece_product<2>(X, Z, out);
+    piece_product<3>(X, Z, out); piece_product<4>(X, Z, out); piece_product<5>(X, Z, out);
+}
+// Portion K (of 16) of the trailing products of block step KB - 1 that were left pending: A_ij -= U_i^T U_j for
+// KB <= ib <= jb < VW except (KB, KB); piece product outermost, so consecutive MFMAs go to different tiles.
+template <int VW, int KB, int K, int PR>
+__device__ __forceinline__ void pending_piece(f32x4 (&T)[Geo<VW>::NT], const TilePieces (&U)[VW], const TilePieces (&nU)[VW],
+                                              int &m) {
+    constexpr int n = VW - KB, TOTAL = 6 * (n * (n + 1) / 2 - 1), PER = (TOTAL + 15) / 16;
+#pragma unroll
+    for (int ib = KB; ib < VW; ++ib)
+#pragma unroll
+        for (int jb = ib; jb < VW; ++jb) {
+            if (ib == KB && jb == KB) continue;
+            if (m >= K * PER && m < (K + 1) * PER) piece_product<PR>(nU[ib], U[jb], T[tile_index(ib, jb, VW)]);
+            ++m;
+        }
+}
+template <int VW, int KB, int K>
+__device__ __forceinline__ void pending_products(f32x4 (&T)[Geo<VW>::NT], const TilePieces (&U)[VW], const TilePieces (&nU)[VW]) {
+    int m = 0;
+    pending_piece<VW, KB, K, 0>(T, U, nU, m); pending_piece<VW, KB, K, 1>(T, U, nU, m);
+    pending_piece<VW, KB, K, 2>(T, U, nU, m); pending_piece<VW, KB, K, 3>(T, U, nU, m);
+    pending_piece<VW, KB, K, 4>(T, U, nU, m); pending_piece<VW, KB, K, 5>(T, U, nU, m);
+}
+template <int VW, int KB>
+struct PendingFiller {
+    f32x4 (&T)[Geo<VW>::NT];
+    const TilePieces (&U)[VW];
+    const TilePieces (&nU)[VW];
+    template <typename Kc> __device__ __forceinline__ void operator()(Kc) const {
+        if constexpr (KB > 0 && KB + 1 < VW) {
+            pending_products<VW, KB, Kc::value>(T, U, nU);
+            __builtin_amdgcn_sched_barrier(0);      // a portion stays with its elimination step
+        }
+    }
+};
+// block step KB: U / nU hold the pieces of block row KB - 1 on entry, of block row KB on return
+template <int VW, int KB>
+__device__ __forceinline__ void solve_block_step_bf16(f32x4 (&T)[Geo<VW>::NT], float (&b)[VW], float (&zcol)[VW],
+                                                      float (&pend)[VW], TilePieces (&U)[VW], TilePieces (&nU)[VW],
+                                                      bool &ok, const int lane) {
+    const f32x4 X = diag_inverse_factor(T[tile_index(KB, KB, VW)], lane, ok, PendingFiller<VW, KB>{T, U, nU});
+    T[tile_index(KB, KB, VW)] = X;      // the diagonal tile is dead once factored: its slot keeps X for the back substitution
+    if constexpr (KB + 1 < VW) {
+        const TilePieces Xp = split_tile(X);
+#pragma unroll
+        for (int jb = KB + 1; jb < VW; ++jb) {      // panel solves U_kj = X^T A_kj
+            const TilePieces Zp = split_tile(T[tile_index(KB, jb, VW)]);
+            f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f};
+            tile_xtz_pieces(Xp, Zp, u);
+            T[tile_index(KB, jb, VW)] = u;
+            U[jb] = split_tile(u);
+            nU[jb] = negated(U[jb]);
+        }
+        // the next diagonal tile's update at once: its elimination starts the next step
+        tile_xtz_pieces(nU[KB + 1], U[KB + 1], T[tile_index(KB + 1, KB + 1, VW)]);
+    }
+    if constexpr (KB > 0) b[KB] -= grp_sum4(pend[KB]);
+    zcol[KB] = tile_xt_v(X, vec_col_to_row(b[KB], lane));          // z_kb = U_kk^{-T} b_kb
+    const f32x4 zrow = vec_col_to_row(zcol[KB], lane);
+#pragma unroll
+    for (int ib = KB + 1; ib < VW; ++ib) {
+        const f32x4 Ui = T[tile_index(KB, ib, VW)];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pend[ib] = fmaf(Ui[r], zrow[r], pend[ib]);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // block steps stay in order: bounds the live ranges
+}
+template <int VW, int... KBs>
+__device__ __forceinline__ void solve_block_steps_bf16(f32x4 (&T)[Geo<VW>::NT], float (&b)[VW], float (&zcol)[VW],
+                                                       float (&pend)[VW], TilePieces (&U)[VW], TilePieces (&nU)[VW],
+                                                       bool &ok, const int lane, std::integer_sequence<int, KBs...>) {
+    (solve_block_step_bf16<VW, KBs>(T, b, zcol, pend, U, nU, ok, lane), ...);
+}
+template <int VW>
+__device__ __forceinline__ bool blocked_solve_bf16(f32x4 (&T)[Geo<VW>::NT], float (&b)[VW], float (&x)[VW], const int lane) {
+    float zcol[VW], pend[VW];
+#pragma unroll
+    for (int t = 0; t < VW; ++t) pend[t] = 0.f;
+    TilePieces U[VW], nU[VW];
+    bool ok = true;
+    solve_block_steps_bf16<VW>(T, b, zcol, pend, U, nU, ok, lane, std::make_integer_sequence<int, VW>{});
+    back_substitute<VW>(T, zcol, x, lane);
     return ok;
 }
 
@@ -724,7 +887,11 @@ __device__ __forceinline__ float solve_row_formed(f32x4 (&acc)[Geo<VW>::NT], flo
         for (int t = 0; t < VW; ++t) x[t] = has_b ? xold[t] : 0.f;
         ok = has_b ? tiles_cg<VW>(acc, bacc, x, cg_steps, lane) : true;
     } else {
-        ok = blocked_solve<VW>(acc, bacc, x, lane);
+#ifndef ALS_SOLVE_BF16_MIN_VW
+#define ALS_SOLVE_BF16_MIN_VW 8
+#endif
+        if constexpr (VW >= ALS_SOLVE_BF16_MIN_VW) ok = blocked_solve_bf16<VW>(acc, bacc, x, lane);
+        else ok = blocked_solve<VW>(acc, bacc, x, lane);
     }
     float d = 0.f;
     if (lane < 16) {
