@@ -31,6 +31,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak
+MFMA_F32_PEAK_TFLOPS = 157.3      # dense float32 matrix-core peak (256 CUs x 256 flops per cycle x 2.4 GHz)
+
+
+def algorithmic_flops(nnz, rows, f):
+    """float32-equivalent flops of one exact half-sweep: per stored entry the rank-1 update of the symmetric f x f
+    normal matrix (f (f+1) / 2 multiply-adds) and of b (f), per row the Cholesky factorisation (f^3 / 3 flops) and the
+    two triangular solves (2 f^2)."""
+    return nnz * (f * (f + 1) + 2 * f) + rows * (f ** 3 / 3.0 + 2.0 * f * f)
 
 
 def parse():
@@ -289,8 +297,110 @@ def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel,
         "bytes_per_launch": (bytes_u + bytes_i) / 2,
         "user_rows": csr_u.shape[0], "item_rows": csr_i.shape[0],
     }
+    if not cg:
+        fl = algorithmic_flops(csr_u.nnz, csr_u.shape[0], f) + algorithmic_flops(csr_i.nnz, csr_i.shape[0], f)
+        res["mfma"] = mfma_view(fl / 2, (bytes_u + bytes_i) / 2, (ku + ki) / 2)
     del eng, csr_u, csr_i, X, Y
     return res, shards, (Xh, Yh, wl)
+
+
+def mfma_view(flops_per_launch, bytes_per_launch, launch_ms):
+    """The same launches against the float32 matrix-core roof: above 157.3 / 8 = 19.7 flops per byte the exact
+    half-sweep is bound by arithmetic, not by HBM (f = 128: 38 flops per byte on MovieLens-like rows, 58 on rows of
+    about 100 entries, where the f^3 / 3 of the solve weighs as much as the accumulation)."""
+    tf = flops_per_launch / (launch_ms * 1e-3) / 1e12
+    return {"bound_by": "mfma" if flops_per_launch / bytes_per_launch > MFMA_F32_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS else "hbm",
+            "flops_per_byte": flops_per_launch / bytes_per_launch,
+            "algorithmic_flops_per_launch": flops_per_launch, "achieved_TFLOPs_f32_equivalent": tf,
+            "peak_TFLOPs_f32_matrix": MFMA_F32_PEAK_TFLOPS, "frac": tf / MFMA_F32_PEAK_TFLOPS}
+
+
+def measure_rank_share(ctx, wl_name, solver, cg_steps, accumulate, row_kernel, steps, warmup, state=None):
+    """What ONE rank of the `of_world`-GPU run of the full matrix executes per iteration, on one GPU: the user
+    half-sweep over its n_users x n_items block, and the item half-sweep over its n_items / of_world items against ALL
+    n_users * of_world users - rows of_world times longer than in the one-block matrix, gathered from the whole user
+    table (5 GB at f = 128).  The all-gathers between the half-sweeps are not part of it (a one-GPU box).  The Gram of
+    the user table is taken over the rank's share of its rows, as in the sharded run."""
+    from recommender_amd import data, ops
+    dev = ctx.dev
+    wl = dict(data.WORKLOADS[wl_name])
+    W, nb, M, f = wl["of_world"], wl["n_users"], wl["n_items"], wl["f"]
+    N, mi = nb * W, M // W
+    if state is None:
+        keys, r = data.synth_pairs(nb, M, wl["nnz"], seed=1234, device=dev, item_seed=1234)
+        U = data.csr_from_sorted_keys(keys, r, nb, M)
+        del keys, r
+        # the rank's items over all users: user activity log-normal over the N users, item popularity over its mi items
+        keys, r = data.synth_pairs(N, mi, wl["nnz"], seed=4321, device=dev)
+        tk, tr = data.transpose_keys(keys, r, N, mi)
+        del keys, r
+        Ut = data.csr_from_sorted_keys(tk, tr, mi, N)
+        del tk, tr
+        torch.cuda.empty_cache()
+        state = (ops.DeviceCSR(U[0], U[1], U[2], (nb, M), dev),
+                 ops.DeviceCSR(Ut[0], Ut[1], Ut[2], (mi, N), dev, chunk_nnz=2048 * 4))
+    csr_u, csr_i = state
+    g = torch.Generator(device=dev); g.manual_seed(42)
+    X = torch.randn((N, f), generator=g, device=dev) / np.sqrt(f)
+    Y = torch.randn((M, f), generator=g, device=dev) / np.sqrt(f)
+    cache_Y, cache_X = ops.GramCache(f, wl["lamb"], dev), ops.GramCache(f, wl["lamb"], dev)
+    ops.gram(X, wl["lamb"], out=cache_X)            # the other ranks' rows of X do not change in this model
+    dX = torch.zeros(1, dtype=torch.float64, device=dev); dY = torch.zeros(1, dtype=torch.float64, device=dev)
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    cg = solver == "cg"
+    base = dict(accumulate=accumulate, row_kernel=row_kernel)
+    taps = {"users": [], "items": []}
+
+    def sweep(csr, opp, cache, own, d, which, timed):
+        opts = ops.sweep_opts(**base)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); e1.record()
+            taps[which].append((e0, e1))
+            opts = ops.sweep_opts(tap=(e0, e1), **base)
+        if cg:
+            ops.half_sweep_cg(csr, opp, cache, own, wl["alpha"], cg_steps, absdiff=d, info=info, opts=opts)
+        else:
+            ops.half_sweep(csr, opp, cache, own, wl["alpha"], absdiff=d, info=info, opts=opts)
+
+    def step(timed):
+        ops.gram(Y, wl["lamb"], out=cache_Y)
+        sweep(csr_u, Y, cache_Y, X[:nb], dX, "users", timed)
+        ops.gram_partials(X, 0, nb)                 # this rank's share of the user table's Gram partials
+        sweep(csr_i, X, cache_X, Y[:mi], dY, "items", timed)
+
+    for _ in range(warmup):
+        step(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if int(info.item()) != 0 and not os.environ.get("ALS_BENCH_IGNORE_INFO"):
+        raise SystemExit("non positive definite row systems: %d" % int(info.item()))
+    ku = sum(e0.elapsed_time(e1) for e0, e1 in taps["users"]) / steps
+    ki = sum(e0.elapsed_time(e1) for e0, e1 in taps["items"]) / steps
+    bu = csr_u.nnz * (8 + 4 * f) + csr_u.shape[0] * (8 + 4 * f)
+    bi = csr_i.nnz * (8 + 4 * f) + csr_i.shape[0] * (8 + 4 * f)
+    res = {"workload": "%s: one rank's share of %d users x %d items on %d GPUs, f=%d: user half-sweep %d x %d (%d nnz), item "
+                       "half-sweep %d x %d (%d nnz); %s; exchanges not included"
+                       % (wl_name, N, M, W, f, nb, M, csr_u.nnz, mi, N, csr_i.nnz,
+                          "%d conjugate-gradient steps per row (formed matrix)" % cg_steps if cg else
+                          "exact Cholesky solve, %s accumulate" % accumulate),
+           "f": f, "solver": solver, "cg_steps": cg_steps if cg else None, "steps": steps,
+           "nnz_per_s": (csr_u.nnz + csr_i.nnz) * steps / dt, "ms_per_step": dt / steps * 1e3,
+           "launch_ms": {"user_sweep": ku, "item_sweep": ki},
+           "achieved_GBs": (bu + bi) / ((ku + ki) * 1e-3) / 1e9,
+           "frac": (bu + bi) / ((ku + ki) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "frac_per_launch": {"user_sweep": bu / (ku * 1e-3) / 1e9 / HBM_PEAK_GBS, "item_sweep": bi / (ki * 1e-3) / 1e9 / HBM_PEAK_GBS},
+           "algorithmic_bytes_per_launch": (bu + bi) / 2, "traffic": None,
+           "rows_this_rank": {"user": csr_u.shape[0], "item": csr_i.shape[0]}}
+    if not cg:
+        fl = algorithmic_flops(csr_u.nnz, csr_u.shape[0], f) + algorithmic_flops(csr_i.nnz, csr_i.shape[0], f)
+        res["mfma"] = mfma_view(fl / 2, (bu + bi) / 2, (ku + ki) / 2)
+    del X, Y
+    return res, state
 
 
 def pmc_traffic(key):
@@ -332,6 +442,23 @@ def main():
             torch.distributed.init_process_group("nccl", device_id=ctx.dev)
         ctx.group = torch.distributed.group.WORLD
 
+    from recommender_amd import data as _data
+    if "of_world" in _data.WORKLOADS.get(args.workload, {}):       # one rank's share of a sharded run, by itself
+        if world != 1:
+            raise SystemExit("%s models one rank of a sharded run on one GPU: --gpus 1" % args.workload)
+        r, _ = measure_rank_share(ctx, args.workload, args.solver, args.cg_steps, args.accumulate, args.row_kernel,
+                                  args.steps, args.warmup)
+        print(json.dumps({"metric": "ALS nnz/sec (2*nnz per iteration; iterations/sec in iters_per_s)",
+                          "value": r["nnz_per_s"], "unit": "nnz/s", "iters_per_s": 1e3 / r["ms_per_step"], "n_gpus": 1,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "synthetic", "config": {"workload": r["workload"]},
+                          "roofline": {"bound": "hbm", "achieved": r["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": r["frac"], "frac_per_launch": r["frac_per_launch"], "traffic": None,
+                                       "launch_ms": r["launch_ms"],
+                                       "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
+                                       "mfma_view": r.get("mfma")}}), flush=True)
+        return
     head, shards, (Xh, Yh, wl) = measure(ctx, args.workload, args.factors, args.solver, args.cg_steps, args.cg_form,
                                          args.accumulate, args.row_kernel, args.steps, args.warmup)
     f = head["f"]
@@ -359,9 +486,26 @@ def main():
                              "traffic": pmc_traffic("%s_f%d%s" % (wname, r["f"], "" if solver != "cg" else
                                                                   "_cg" if cgs == args.cg_steps else "_cg%d" % cgs)),
                              "rows_this_rank": {"user": r["user_rows"], "item": r["item_rows"]}})
+                if "mfma" in r:
+                    also[-1]["mfma"] = r["mfma"]
             except Exception as exc:            # a failing extra point must not cost the headline line
                 also.append({"workload": wname, "f": ff, "solver": solver, "cg_steps": cgs or None, "error": repr(exc)})
                 prev = None
+            torch.cuda.empty_cache()
+
+        if plan and world == 1:
+            # the eight-GPU configuration as one of its ranks runs it (long item rows, the whole user table)
+            prev = None
+            torch.cuda.empty_cache()
+            state = None
+            for (solver, cgs) in (("cholesky", 0), ("cg", args.cg_steps)):
+                try:
+                    r, state = measure_rank_share(ctx, "c3_rank_syn", solver, cgs, args.accumulate, args.row_kernel,
+                                                  args.also_steps, 1, state)
+                    also.append(r)
+                except Exception as exc:
+                    also.append({"workload": "c3_rank_syn", "solver": solver, "error": repr(exc)})
+            del state
             torch.cuda.empty_cache()
 
     ranks = None
@@ -392,6 +536,8 @@ def main():
                          "launch_ms": head["launch_ms"],
                          "algorithmic_bytes_per_launch": head["bytes_per_launch"]},
         }
+        if "mfma" in head:
+            out["roofline"]["mfma_view"] = head["mfma"]
         if world > 1:
             out["distributed"] = {"backend": backend, "world_size": torch.distributed.get_world_size(), "ranks": ranks}
         if also:

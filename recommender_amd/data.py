@@ -95,6 +95,9 @@ WORKLOADS = {
     # stored entries (balance_users), not at the block boundaries: ranks own different numbers of rows.
     "c3_shard_syn": dict(n_users=1250000, n_items=1000000, nnz=125000000, f=128, lamb=0.01, alpha=40.0, iters=15,
                          init="device", block_jitter=0.1, balance_users=True),
+    # what one rank of the eight-GPU run of that matrix executes: its 1.25 M users over all 1 M items, and its
+    # 125 000 items over all 10 M users (item rows eight times longer, the whole 5 GB user table gathered from)
+    "c3_rank_syn": dict(n_users=1250000, n_items=1000000, nnz=125000000, f=128, lamb=0.01, alpha=40.0, of_world=8),
     # one GPU's eighth of the 50 M x 5 M, 4 B-entry matrix (f=256, conjugate-gradient solver)
     "c4_shard_syn": dict(n_users=6250000, n_items=5000000, nnz=500000000, f=256, lamb=0.01, alpha=40.0, iters=15,
                          init="device", solver="cg"),

@@ -128,6 +128,65 @@ def test_c3_shard_user_and_item_half_sweeps_at_full_size():
     _check_side(ctx, Ut, (M, N), X1, Y0, seed=4, min_longest=2048)
 
 
+def test_c3_rank_item_half_sweep_against_the_whole_user_table():
+    """The item half-sweep as ONE rank of the eight-GPU run of the 10 M x 1 M matrix executes it (f = 128): its
+    125 000 items against all 10 M users - rows eight times longer than in the one-block matrix (the longest are cut into
+    hundreds of chunks), gathered from the whole 5 GB user table.  Sampled rows (up to 300 000 entries long) against the
+    float64 oracle, which gets the rows of the user table that the sample touches and the Gram of the whole table;
+    the reported change, repeatability, two row shards = whole."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import recommender_amd as ra
+    from recommender_amd import data
+    from recommender_amd.als import balanced_ranges
+    wl = data.WORKLOADS["c3_rank_syn"]
+    W, f = wl["of_world"], wl["f"]
+    N, mi = wl["n_users"] * W, wl["n_items"] // W
+    keys, r = data.synth_pairs(N, mi, wl["nnz"], seed=4321, device="cuda")
+    tk, tr = data.transpose_keys(keys, r, N, mi)
+    del keys, r
+    Ut = data.csr_from_sorted_keys(tk, tr, mi, N)
+    del tk, tr
+    g = torch.Generator(device="cuda"); g.manual_seed(31)
+    X = torch.randn((N, f), generator=g, device="cuda") / f ** 0.5
+    Y0 = torch.randn((mi, f), generator=g, device="cuda") / f ** 0.5
+    csr = ra.DeviceCSR(Ut[0], Ut[1], Ut[2], (mi, N), "cuda", chunk_nnz=8192)
+    gc = ra.gram(X, LAMB)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    Y = Y0.clone()
+    d = ra.half_sweep(csr, X, gc, Y, ALPHA, info=info)
+    assert int(info.item()) == 0
+    assert float(d.item()) == pytest.approx(float((Y0.double() - Y.double()).abs().sum().item()), rel=1e-6)
+    ptr, col, val = (t.cpu().numpy() for t in Ut)
+    lens = np.diff(ptr)
+    assert lens.max() > 100 * 8192                       # rows of hundreds of chunks exist
+    order = np.argsort(-lens, kind="stable")
+    capped = order[lens[order] <= 300_000]
+    rng = np.random.default_rng(9)
+    rows = np.unique(np.concatenate([capped[:3], order[-5:], rng.choice(mi, size=40, replace=False)]))
+    assert lens[rows].max() > 4 * 8192                   # the sample holds rows of several chunks
+    sp, sc, sv = _sub_csr(ptr, col, val, rows)
+    used, sc_local = np.unique(sc, return_inverse=True)
+    Xsub = X[torch.from_numpy(used.astype(np.int64)).cuda()].double().cpu().numpy()
+    G = torch.zeros((f, f), dtype=torch.float64, device="cuda")
+    for r0 in range(0, N, 1 << 20):                      # float64 Gram of the whole table, a slab at a time
+        blk = X[r0:r0 + (1 << 20)].double()
+        G += blk.T @ blk
+    sel = torch.from_numpy(rows).cuda()
+    ref = c_oracle.half_sweep(sp, sc_local.astype(np.int32), sv, Xsub, Y0[sel].double().cpu().numpy(), LAMB, ALPHA,
+                              dtype=np.float64, nthreads=8, Y2=G.cpu().numpy())
+    got = Y[sel].cpu().numpy().astype(np.float64)
+    assert _rel(got, ref) < 1e-4, _rel(got, ref)
+    Y2 = Y0.clone()
+    d2 = ra.half_sweep(csr, X, gc, Y2, ALPHA)
+    assert torch.equal(Y, Y2) and float(d.item()) == float(d2.item())
+    b = [int(x) for x in balanced_ranges(ptr, 2)]
+    Y3 = Y0.clone()
+    for r0, r1 in zip(b[:-1], b[1:]):
+        ra.half_sweep(csr.row_range(r0, r1), X, gc, Y3[r0:r1], ALPHA)
+    assert torch.equal(Y, Y3)
+
+
 def test_c4_slice_cg_forms_at_f256():
     """A slice of one GPU's eighth of the 50 M x 5 M matrix (every item, 1/20 of the shard's users) at f = 256: three
     conjugate-gradient steps in the formed-matrix form (a row's tiles over 4 wavefronts) and in the lock-step form
