@@ -1162,6 +1162,9 @@ __global__ __launch_bounds__(256) void sum_to_double_kernel(const T *__restrict_
 }
 
 #include "als_wide_row.inc"
+#ifndef ALS_STREAM_CHUNKS_MIN_PER_WAVE
+#define ALS_STREAM_CHUNKS_MIN_PER_WAVE 4      // chunk items per resident wave from which they go to the stream kernel
+#endif
 #include "als_row_stream.inc"
 
 // ----------------------------------------------------------------------------- host helpers
@@ -1262,7 +1265,15 @@ static int32_t half_sweep_impl(const SweepParams &p, int64_t n_rows, int64_t n_i
             ALS_HIP_CHECK(hipGetDevice(&dev));
             ALS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
             cus = std::max(cus, 1);
-            if (n_chunk_items > 0) {
+            // The chunk items of long rows: as streams too once every resident wave gets several of them (their static
+            // shares are then even; with few, the one-wave kernel's workgroups, handed out as SIMDs fall free, balance
+            // better).  Same partial sums bit for bit either way.
+            if (n_chunk_items >= ALS_STREAM_CHUNKS_MIN_PER_WAVE * 4 * (int64_t)cus) {
+                const dim3 grid((unsigned)(4 * cus)), block(64);
+                if (p.f == 128) hipLaunchKernelGGL((sweep_stream_kernel<true, true>), grid, block, 0, st, p, (int64_t)0, n_chunk_items);
+                else hipLaunchKernelGGL((sweep_stream_kernel<false, true>), grid, block, 0, st, p, (int64_t)0, n_chunk_items);
+                ALS_HIP_CHECK(hipGetLastError());
+            } else if (n_chunk_items > 0) {
                 const dim3 grid((unsigned)n_chunk_items), block(64);
                 if (p.f == 128) hipLaunchKernelGGL((sweep_items_kernel<VW, true, true, true>), grid, block, 0, st, p);
                 else hipLaunchKernelGGL((sweep_items_kernel<VW, true, false, true>), grid, block, 0, st, p);

@@ -2,7 +2,7 @@
 
 Both kernels cut, multiply and solve in the same order, so their factors and |delta| must be the same bits; the
 oracle comparison (float64 restatement of reclibwh/core/ALS.py:70-118) bounds both.  Shapes cover rows longer than
-chunk_nnz (their chunk items stay on the one-wave kernel), empty rows, fewer rows than resident waves, and f < 128
+chunk_nnz (few chunk items stay on the one-wave kernel, many go through the stream kernel too), empty rows, fewer rows than resident waves, and f < 128
 (masked row halves).
 """
 import numpy as np
@@ -56,6 +56,50 @@ def test_stream_equals_wave_and_oracle(f, shape):
             out[(rk, cg)] = res[0]
     scale = np.abs(ref).max()
     assert np.abs(out[("stream", 0)][0] - ref).max() / scale < 1e-4      # the tolerance the factors are held to
+    for cg in (0, 3):
+        assert np.array_equal(out[("stream", cg)][0], out[("wave", cg)][0])
+        assert out[("stream", cg)][1] == out[("wave", cg)][1]
+
+
+@pytest.mark.parametrize("f", [128, 100])
+def test_stream_takes_the_chunk_items_when_there_are_many(f):
+    """With several chunk items per resident wavefront (here ~5 000 of 64 entries each, from 150 rows of about 2 100
+    entries) the long rows' chunks go through the stream kernel as well, which stores their partial sums instead of
+    solving: the same bits as the one-wave kernel for factors and |delta|, exact solve and conjugate gradients."""
+    import recommender_amd as ra
+    from oracle import c_oracle
+
+    rng = np.random.default_rng(77 + f)
+    N, M, chunk = 1300, 6000, 64
+    lens = rng.integers(0, 60, size=N).astype(np.int64)
+    long_rows = rng.choice(N, size=150, replace=False)
+    lens[long_rows] = rng.integers(2040, 2120, size=150)
+    lens[long_rows[:4]] = [2048, 2049, 2047, 2080]            # whole chunks, one entry over, one under, a half block over
+    ptr = np.zeros(N + 1, dtype=np.int64)
+    np.cumsum(lens, out=ptr[1:])
+    ind = np.concatenate([np.sort(rng.choice(M, size=l, replace=False)) for l in lens]).astype(np.int32)
+    dat = (rng.integers(1, 11, size=ptr[-1]) * 0.5).astype(np.float32)
+    Y0 = rng.normal(0, 1 / np.sqrt(f), size=(M, f)).astype(np.float32)
+    X0 = rng.normal(0, 1 / np.sqrt(f), size=(N, f)).astype(np.float32)
+    ref = c_oracle.half_sweep(ptr, ind, dat, Y0, X0, 0.01, 40.0, dtype=np.float64, nthreads=8)
+    csr = ra.DeviceCSR(ptr, ind, dat, (N, M), "cuda", chunk_nnz=chunk)
+    assert csr.n_items - (N - csr.n_long) >= 4 * 4 * torch.cuda.get_device_properties(0).multi_processor_count
+    Y = torch.from_numpy(Y0).cuda()
+    gc = ra.gram(Y, 0.01)
+    out = {}
+    for rk in ("wave", "stream"):
+        for cg in (0, 3):
+            X = torch.from_numpy(X0).cuda()
+            info = torch.zeros(1, dtype=torch.int32, device="cuda")
+            o = ra.ops.sweep_opts(row_kernel=rk)
+            if cg:
+                d = ra.ops.half_sweep_cg(csr, Y, gc, X, 40.0, cg, info=info, form="matrix", opts=o)
+            else:
+                d = ra.half_sweep(csr, Y, gc, X, 40.0, info=info, opts=o)
+            torch.cuda.synchronize()
+            assert int(info.item()) == 0
+            out[(rk, cg)] = (X.cpu().numpy(), float(d.item()))
+    assert np.abs(out[("stream", 0)][0] - ref).max() / np.abs(ref).max() < 1e-4
     for cg in (0, 3):
         assert np.array_equal(out[("stream", cg)][0], out[("wave", cg)][0])
         assert out[("stream", cg)][1] == out[("wave", cg)][1]
