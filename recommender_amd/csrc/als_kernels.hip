@@ -1060,7 +1060,10 @@ __global__ __launch_bounds__(64) void gram_chunk_kernel(const float *__restrict_
     for (int t = 0; t < G::NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < VW; ++t) bacc[t] = 0.f;
-    if (e > s) accumulate_range<VW, VEC, FULL, false>(acc, bacc, nullptr, nullptr, s, e, Y, ld, f, 1.0f, lane);
+#ifndef ALS_GRAM_SPLIT_MIN_VW
+#define ALS_GRAM_SPLIT_MIN_VW 4      // f > 32: the bf16 x 3 form of the accumulate (weights 1), as in the sweeps
+#endif
+    if (e > s) accumulate_range<VW, VEC, FULL, false, (VW >= ALS_GRAM_SPLIT_MIN_VW)>(acc, bacc, nullptr, nullptr, s, e, Y, ld, f, 1.0f, lane);
     float *P = out + (int64_t)blockIdx.x * (G::TQ * 64);
 #pragma unroll
     for (int t = 0; t < G::NT; ++t)
