@@ -6,14 +6,18 @@
 #include <cstdio>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
 #define ITERS 4000
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k(float *out, float s) {
+__global__ __launch_bounds__(768) void k(float *out, float s) {
     float a = threadIdx.x * 0.001f + 1.0f, b = s, c = s * 0.5f, d = a + 1.f, e = a + 2.f, f = a + 3.f;
     float g0 = a + 4.f, g1 = a + 5.f, g2 = a + 6.f, g3 = a + 7.f;
     f32x4 acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
     bf16x4 pa = {1, 2, 3, 4};
+    bf16x8 pb = {1, 2, 3, 4, 5, 6, 7, 8};
+    f32x4 accs[8];
+    for (int q = 0; q < 8; ++q) accs[q] = f32x4{0, 0, 0, 0};
     int addr = ((threadIdx.x & 15) + 16) * 4;
     for (int it = 0; it < ITERS; ++it) {
         if constexpr (MODE == 0) {          // 8 dependent fma
@@ -75,12 +79,37 @@ __global__ __launch_bounds__(256) void k(float *out, float s) {
                          "v_fmac_f32_dpp %0, %0, %4 row_newbcast:5 row_mask:0xf bank_mask:0xf\n v_fmac_f32_dpp %1, %1, %4 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
                          "v_fmac_f32_dpp %2, %2, %4 row_newbcast:5 row_mask:0xf bank_mask:0xf\n v_fmac_f32_dpp %3, %3, %4 row_newbcast:5 row_mask:0xf bank_mask:0xf"
                          : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3), "+v"(d), "+v"(e), "+v"(addr) :: "s20", "vcc");
+        } else if constexpr (MODE == 15) {  // 8 independent bf16 16x16x16 MFMAs (8 accumulators)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) accs[q] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, pa, accs[q], 0, 0, 0);
+        } else if constexpr (MODE == 16) {  // 8 independent bf16 16x16x32 MFMAs (8 accumulators)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) accs[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pb, pb, accs[q], 0, 0, 0);
+        } else if constexpr (MODE == 17) {  // 8 independent bf16 16x16x32 MFMAs + 16 independent fma interleaved
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                accs[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pb, pb, accs[q], 0, 0, 0);
+                asm volatile("v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3" : "+v"(g0), "+v"(g1) : "v"(b), "v"(c));
+            }
+        } else if constexpr (MODE == 18) {  // 8 independent bf16 16x16x16 MFMAs + 16 independent fma interleaved
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                accs[q] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, pa, accs[q], 0, 0, 0);
+                asm volatile("v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3" : "+v"(g0), "+v"(g1) : "v"(b), "v"(c));
+            }
+        } else if constexpr (MODE == 19) {  // 8 x (s_mov + s_nop): scalar instructions in the one wave's stream
+            asm volatile("s_mov_b32 s20, 1\n s_nop 0\n s_mov_b32 s20, 2\n s_nop 0\n s_mov_b32 s20, 3\n s_nop 0\n s_mov_b32 s20, 4\n s_nop 0\n"
+                         "s_mov_b32 s20, 1\n s_nop 0\n s_mov_b32 s20, 2\n s_nop 0\n s_mov_b32 s20, 3\n s_nop 0\n s_mov_b32 s20, 4\n s_nop 0" ::: "s20");
+        } else if constexpr (MODE == 20) {  // 4 x (2 dot2c bf16), dependent
+            asm volatile("v_dot2c_f32_bf16 %0, %1, %2\n v_dot2c_f32_bf16 %0, %1, %2\n v_dot2c_f32_bf16 %0, %1, %2\n v_dot2c_f32_bf16 %0, %1, %2\n"
+                         "v_dot2c_f32_bf16 %0, %1, %2\n v_dot2c_f32_bf16 %0, %1, %2\n v_dot2c_f32_bf16 %0, %1, %2\n v_dot2c_f32_bf16 %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
         } else if constexpr (MODE == 14) {  // 4 fmac_dpp only, dependent through the DPP source (2 registers alternating)
             asm volatile("v_fmac_f32_dpp %0, %0, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf\n s_nop 1\n v_fmac_f32_dpp %1, %0, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
                          "v_fmac_f32_dpp %0, %1, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf\n s_nop 1\n v_fmac_f32_dpp %1, %0, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf\n s_nop 1"
                          : "+v"(g0), "+v"(g1) : "v"(c));
         }
     }
+    for (int q = 0; q < 8; ++q) a += accs[q][0] + accs[q][3];
     float r = a + d + e + f + g0 + g1 + g2 + g3 + b + c + acc[0] + acc[1] + acc[2] + acc[3] + acc2[0] + acc2[1] + (float)addr;
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
@@ -113,6 +142,12 @@ int main() {
         run<8>("8 dependent bf16 16x16x16 MFMA", threads, d, unit);
         run<9>("8 dependent fp32 16x16x4 MFMA", threads, d, unit);
         run<10>("8 bf16 16x16x16 MFMA (2 accumulators) + 16 fma interleaved", threads, d, unit);
+        run<15>("8 independent bf16 16x16x16 MFMA", threads, d, unit);
+        run<18>("8 independent bf16 16x16x16 MFMA + 16 fma interleaved", threads, d, unit);
+        run<16>("8 independent bf16 16x16x32 MFMA", threads, d, unit);
+        run<17>("8 independent bf16 16x16x32 MFMA + 16 fma interleaved", threads, d, unit);
+        run<19>("8 x (s_mov, s_nop 0)", threads, d, unit);
+        run<20>("8 dependent v_dot2c_f32_bf16", threads, d, unit);
         run<11>("elimination step, two tiles: bpermute, newton, 8 fmac_dpp", threads, d, unit);
         run<13>("elimination step, one tile: bpermute, 4 fmac_dpp", threads, d, unit);
         run<12>("elimination step, one tile: swaps, 4 fmac_dpp", threads, d, unit);
