@@ -394,7 +394,8 @@ def measure_rank_share(ctx, wl_name, solver, cg_steps, accumulate, row_kernel, s
            "achieved_GBs": (bu + bi) / ((ku + ki) * 1e-3) / 1e9,
            "frac": (bu + bi) / ((ku + ki) * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "frac_per_launch": {"user_sweep": bu / (ku * 1e-3) / 1e9 / HBM_PEAK_GBS, "item_sweep": bi / (ki * 1e-3) / 1e9 / HBM_PEAK_GBS},
-           "algorithmic_bytes_per_launch": (bu + bi) / 2, "traffic": None,
+           "algorithmic_bytes_per_launch": (bu + bi) / 2,
+           "traffic": pmc_traffic("%s_f%d" % (wl_name, f)) if not cg else None,
            "rows_this_rank": {"user": csr_u.shape[0], "item": csr_i.shape[0]}}
     if not cg:
         fl = algorithmic_flops(csr_u.nnz, csr_u.shape[0], f) + algorithmic_flops(csr_i.nnz, csr_i.shape[0], f)

@@ -44,8 +44,8 @@ for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
         print("  " + k + "  " + "  ".join("%s=%.4g" % (c, sum(v) / len(v)) for c, v in sorted(agg[k].items())) +
               "  (n=%d)" % len(next(iter(agg[k].values()))))
 
-# HBM traffic of one half-sweep's per-row kernels, for bench.py's roofline.traffic: every kernel between the taps runs
-# once per half-sweep, so the per-launch figure is the sum over them of the per-dispatch average.  FETCH_SIZE and
+# HBM traffic of one half-sweep's per-row kernels, for bench.py's roofline.traffic: the sum over the kernels between
+# the taps of their traffic per half-sweep.  FETCH_SIZE and
 # WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies the 128-byte requests of 16-byte-per-lane loads (global_load and
 # LDS-DMA alike - the sweep's gathers) at 64 bytes, so the read side is doubled; WRITE_SIZE is exact.  Infinity-Cache
 # hits are counted in, not excluded.
@@ -57,19 +57,29 @@ for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
     cc = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True) if os.path.isdir(d) else []
     for f in cc:
         vals = collections.defaultdict(lambda: collections.defaultdict(list))
+        n_sum = collections.Counter()
         for row in csv.DictReader(open(f)):
             k = short(row["Kernel_Name"])
             if k in ROW_KERNELS:
                 vals[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
-        for k, v in vals.items():
-            if "FETCH_SIZE" in v: fetch[k] = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"])
-            if "WRITE_SIZE" in v: write[k] = sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
+            elif k == "sum_to_double_kernel":          # two launches end every half-sweep (the |delta| sum)
+                n_sum[row["Counter_Name"]] += 1
+        # a kernel can run more than once per half-sweep (the stream kernel: the long rows' chunk items, then the
+        # whole rows) or in some half-sweeps only (the long rows' kernels), so: total over its dispatches / number of
+        # half-sweeps
+        for name in ("FETCH_SIZE", "WRITE_SIZE"):
+            have = {k: v[name] for k, v in vals.items() if name in v}
+            if not have:
+                continue
+            n_half = n_sum[name] // 2 if n_sum[name] >= 2 else min(len(x) for x in have.values())
+            for k, x in have.items():
+                (fetch if name == "FETCH_SIZE" else write)[k] = sum(x) / n_half
 if fetch and write:
     ft, wt = sum(fetch.values()), sum(write.values())
     t = {"kernels": sorted(fetch), "FETCH_SIZE_KiB_avg": ft, "WRITE_SIZE_KiB_avg": wt,
          "FETCH_SIZE_KiB_by_kernel": fetch, "WRITE_SIZE_KiB_by_kernel": write,
          "hbm_bytes_per_launch": ft * 1024 * 2 + wt * 1024,
-         "note": "sum over the per-row kernels of a half-sweep of their per-dispatch averages (user and item sweeps averaged); "
+         "note": "sum over the per-row kernels of a half-sweep of their traffic per half-sweep (user and item sweeps averaged); "
                  "read side = FETCH_SIZE x 2 (gfx950 correction)"}
     json.dump(t, open(os.path.join(out, "pmc_traffic_entry.json"), "w"), indent=1)
     print("== HBM traffic per half-sweep (%s): %.3f GB (fetch x2 %.3f GB + write %.3f GB)" %

@@ -33,6 +33,8 @@ run c3shard_exact_wave   --workload c3_shard_syn --steps 3 --warmup 1 --row-kern
 run c3shard_cg10         --workload c3_shard_syn --steps 3 --warmup 1 --solver cg && \
 run c3shard_cg3          --workload c3_shard_syn --steps 3 --warmup 1 --solver cg --cg-steps 3 && \
 run c3shard_cg3_wave     --workload c3_shard_syn --steps 3 --warmup 1 --solver cg --cg-steps 3 --row-kernel wave && \
+run c3rank_exact         --workload c3_rank_syn --steps 3 --warmup 1 && \
+run c3rank_cg10          --workload c3_rank_syn --steps 3 --warmup 1 --solver cg && \
 run c4shard_cg10         --workload c4_shard_syn --steps 2 --warmup 1 && \
 run c4shard_cg3          --workload c4_shard_syn --steps 2 --warmup 1 --cg-steps 3 && \
 python3 "$ROOT/tools/bench_topk.py" --users 65536 --skip-materialised && \
