@@ -57,16 +57,16 @@ int32_t als_abi_version(void);
  *           significant piece products run on the bf16 matrix cores, accumulated in float32; error
  *           at the level of float32 rounding (the dropped products are < 2^-23 of each term);
  *       ALS_ACCUMULATE_FP32              float32 matrix-core fma chain in CSR order (v_mfma_f32_16x16x4_f32).
- *       Both are deterministic and independent of the launch geometry.  f <= 16 always uses FP32,
- *       as does the Gram.
- *   row_kernel  which per-row kernel handles 64 < f <= 128 (results agree to float32 rounding, each
- *       is reproducible bit for bit):
+ *       Both are deterministic and independent of the launch geometry.  f <= 16 always uses FP32.
+ *       (The Gram of als_gram_f32 takes no options: bf16 x 3 for 32 < f <= 128, float32 otherwise.)
+ *   row_kernel  which per-row kernel handles 64 < f <= 128 (both return the same bits):
  *       ALS_ROW_KERNEL_WAVE       one wavefront owns a row's whole matrix (144 accumulator registers);
  *       ALS_ROW_KERNEL_STREAM     one resident wavefront per SIMD walks its share of the rows as one stream of
  *                                 32-entry blocks: factor rows come by LDS-DMA several blocks ahead, across row
  *                                 boundaries, and a block's matrix products overlap the next block's operand
  *                                 split (bf16 x 3 accumulate, 16-byte aligned factor rows; long rows' chunk
- *                                 items still run on the WAVE kernel);
+ *                                 items go the same way once every resident wavefront gets several, else
+ *                                 they run on the WAVE kernel - the partial sums are the same bits);
  *       ALS_ROW_KERNEL_AUTO       the library's choice.
  *   tap_begin / tap_end  two hipEvent_t handles, or both NULL: recorded on `stream` immediately before
  *       the first and after the last per-row kernel of the call (benchmarks time the kernels with
