@@ -348,12 +348,20 @@ __device__ __forceinline__ void accumulate_range(f32x4 (&acc)[Geo<VW>::NT], floa
             cw = 0.f;
         }
     };
+    // The loads have a FIXED shape: every chunk loads the next chunk's ids and every stage issues the next stage's
+    // factor rows, whether or not they hold entries (past the end every lane reads entry s / row 0 with weight 0, and
+    // stages without entries are not multiplied).  With the issue behind a condition the two ways to the next
+    // stage's arithmetic have different loads pending, hipcc can only wait for all of them (s_waitcnt vmcnt(0)), and
+    // the prefetch of the stage ahead is lost; with one shape it counts (vmcnt(GS)) and the loads overlap the arithmetic.
     load_chunk(s, cur_off, cur_w, cur_cw);
     issue<VW, VEC, FULL>(A, 0, cur_off, cur_w, cur_cw, Y, ld, f, lane);
     for (int64_t base = s; base < e; base += 64) {
         const int64_t nb = base + 64;
         const bool more = nb < e;
-        if (more) load_chunk(nb, nxt_off, nxt_w, nxt_cw);
+#ifdef ALS_CONDITIONAL_ISSUE
+        if (more)
+#endif
+        load_chunk(nb, nxt_off, nxt_w, nxt_cw);
         const int rem = more ? 64 : (int)(e - base);
         const int ng = (rem + 4 * GS - 1) / (4 * GS);   // stages of this chunk that hold entries
 #pragma unroll
@@ -361,8 +369,15 @@ __device__ __forceinline__ void accumulate_range(f32x4 (&acc)[Geo<VW>::NT], floa
             Stage<VW> &cur = (g & 1) ? B : A;
             Stage<VW> &nxt = (g & 1) ? A : B;
             if (g + 1 < NG) {
-                if (ng > g + 1) issue<VW, VEC, FULL>(nxt, g + 1, cur_off, cur_w, cur_cw, Y, ld, f, lane);
-            } else if (more) {   // last stage of a full chunk: rotate to the prefetched chunk
+#ifdef ALS_CONDITIONAL_ISSUE
+                if (ng > g + 1)
+#endif
+                issue<VW, VEC, FULL>(nxt, g + 1, cur_off, cur_w, cur_cw, Y, ld, f, lane);
+            } else
+#ifdef ALS_CONDITIONAL_ISSUE
+            if (more)
+#endif
+            {   // last stage of a chunk: rotate to the prefetched chunk
                 cur_off = nxt_off;
                 cur_w = nxt_w;
                 cur_cw = nxt_cw;
