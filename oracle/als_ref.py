@@ -242,8 +242,8 @@ def rmse(x, y):
 
 
 def compute_auc(rec, test_user, train_user):
-    """eval_utils.py:5-21.  np.setdiff1d SORTS its output, so positions are positions in
-    the id-sorted filtered list, exactly as in the reference."""
+    """eval_utils.py:5-21.  np.setdiff1d(..., assume_unique=True) keeps the order of what remains, so positions
+    are positions in the ranked list with the training items taken out, exactly as in the reference."""
     rec_filt = np.setdiff1d(rec, train_user, assume_unique=True)
     n = len(rec_filt)
     pos = np.nonzero(np.isin(rec_filt, test_user))[0]
@@ -256,7 +256,7 @@ def compute_auc(rec, test_user, train_user):
 
 
 def compute_ap(rec, test_user, train_user):
-    """eval_utils.py:23-37 (same id-sorted quirk as compute_auc)."""
+    """eval_utils.py:23-37 (positions as in compute_auc)."""
     if len(test_user) == 0: return -1
     rec_filt = np.setdiff1d(rec, train_user, assume_unique=True)
     pos = np.nonzero(np.isin(rec_filt, test_user))[0] + 1

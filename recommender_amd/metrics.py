@@ -1,14 +1,17 @@
-"""Evaluation metrics of the reference, host side (they run on a few hundred users per epoch).
+"""Evaluation metrics of the reference.
 
-  compute_ap / compute_auc   reclibwh/utils/eval_utils.py:5-37
-  rmse                       reclibwh/utils/utils.py:58-59
-  users_to_test              reclibwh/core/ALS.py:434-437
-  mean_average_precision     AUCEval.evaluate, reclibwh/core/EvalProto.py:28-62  (the "AUC" the
-                             reference logs to eval.csv is this MAP over the first 200 items)
+  compute_ap / compute_auc        reclibwh/utils/eval_utils.py:5-37   (host, numpy: the reference's own formulas)
+  rmse                            reclibwh/utils/utils.py:58-59
+  users_to_test                   reclibwh/core/ALS.py:434-437
+  mean_average_precision          AUCEval.evaluate, reclibwh/core/EvalProto.py:28-62  (the "AUC" the reference
+                                  logs to eval.csv is this MAP over the first 200 items) - host loop over users
+  mean_average_precision_device   the same number from torch operations on the device that holds the
+                                  recommendations (what RecommenderALS.evaluate uses): no per-user loop, no copy of
+                                  the ranked lists to the host
+  pair_keys / relevant_test_keys  the sorted (user, item) keys the device form looks memberships up in
 
-The reference filters training items with np.setdiff1d, which also SORTS the remaining
-recommendations by item id; ranks are therefore positions in the id-sorted list.  That is
-reproduced here, because eval.csv values are only comparable if it is.
+The reference filters training items with np.setdiff1d(rec, train, assume_unique=True), which keeps the ranked
+order of what remains; a relevant item's rank is its 1-based position in that filtered list.
 """
 import numpy as np
 
@@ -63,3 +66,60 @@ def mean_average_precision(recs, users, train_csr, test_csr, med_score=3.0, lim=
             continue
         vals.append(ap)
     return float(np.mean(vals)) if vals else float("nan")
+
+
+# ----------------------------------------------------------------------------- device form
+def pair_keys(csr, n_items, device, mask=None):
+    """Sorted int64 keys user * n_items + item of the stored entries of a canonical scipy CSR (optionally only those
+    where mask is set), as a tensor on `device`."""
+    import torch
+    rows = np.repeat(np.arange(csr.shape[0], dtype=np.int64), np.diff(csr.indptr))
+    keys = rows * int(n_items) + csr.indices.astype(np.int64)
+    if mask is not None:
+        keys = keys[mask]
+    return torch.from_numpy(np.ascontiguousarray(keys)).to(device)
+
+
+def relevant_test_keys(test_csr, n_items, device, med_score=3.0):
+    """(sorted keys of the test entries rated above med_score, number of such entries per user) on `device`."""
+    import torch
+    mask = test_csr.data > med_score
+    rows = np.repeat(np.arange(test_csr.shape[0], dtype=np.int64), np.diff(test_csr.indptr))
+    counts = np.bincount(rows[mask], minlength=test_csr.shape[0]).astype(np.int64)
+    return pair_keys(test_csr, n_items, device, mask), torch.from_numpy(counts).to(device)
+
+
+def _member(sorted_keys, q):
+    import torch
+    if sorted_keys.numel() == 0:
+        return torch.zeros_like(q, dtype=torch.bool)
+    pos = torch.searchsorted(sorted_keys, q).clamp_(max=sorted_keys.numel() - 1)
+    return sorted_keys[pos] == q
+
+
+def mean_average_precision_device(recs, users, train_keys, rel_keys, rel_counts, n_items, lim=200):
+    """mean_average_precision on tensors: recs [U, >= lim] ranked item ids and users [U] (int64, one device),
+    train_keys / rel_keys / rel_counts from pair_keys / relevant_test_keys.  Per user (EvalProto.py:41-57,
+    eval_utils.py:23-37): the first `lim` recommendations, training items dropped, AP = mean over the relevant items
+    found of (their count so far / their position in the filtered list); users without a relevant test item are
+    skipped, users whose list holds none of theirs count 0."""
+    import torch
+    r = recs[:, :lim].to(torch.int64)
+    keys = users.to(torch.int64)[:, None] * int(n_items) + r
+    kept = ~_member(train_keys, keys)
+    rel = kept & _member(rel_keys, keys)
+    rank = torch.cumsum(kept, 1).to(torch.float64)              # position in the filtered list (where kept)
+    found = torch.cumsum(rel, 1).to(torch.float64)
+    ap_sum = torch.where(rel, found / rank.clamp(min=1.0), torch.zeros_like(rank)).sum(1)
+    p = found[:, -1] if r.shape[1] else torch.zeros(r.shape[0], dtype=torch.float64, device=r.device)
+    ap = torch.where(p > 0, ap_sum / p.clamp(min=1.0), torch.zeros_like(p))
+    counted = rel_counts[users.to(torch.int64)] > 0
+    if not bool(counted.any()):
+        return float("nan")
+    return float(ap[counted].mean().item())
+
+
+def rmse_device(pred, target):
+    """rmse (utils.py:58-59) of two tensors on one device, accumulated in float64."""
+    import torch
+    return float(torch.sqrt(torch.mean((pred.double() - target.double()) ** 2)).item())

@@ -59,6 +59,7 @@ class RecommenderALS:
         self.n_users, self.n_items = n_users, n_items
         self.X = self.Y = None
         self.Utrain = self.Utest = None
+        self._eval_keys = None         # sorted (user, item) keys of the training pairs / relevant test pairs, on the device
         self.engine = None
         self._foldin_cache = None
         self._exclusions = None
@@ -85,6 +86,7 @@ class RecommenderALS:
         if Utrain.nnz and Utrain.data.min() < 0:
             raise ValueError("ratings must be >= 0 (implicit confidence c = 1 + alpha r)")
         self.Utrain = Utrain
+        self._eval_keys = None
         self._exclusions = None
         self.Utest = None if Utest is None else sps.csr_matrix(Utest)
         if self.Utest is not None:
@@ -302,5 +304,22 @@ class RecommenderALS:
         if len(users) == 0:
             return float("nan")
         lim = int(self.config["eval_lim"])
-        recs, _ = self.recommend(users, k=min(lim, self.n_items))
-        return metrics.mean_average_precision(recs, users, self.Utrain, self.Utest, self.config["med_score"], lim)
+        # on the device end to end: fused top-k, then the average precision from torch operations on the ranked ids
+        # (metrics.mean_average_precision is the host loop it is tested against)
+        if self._eval_keys is None:
+            self._eval_keys = (metrics.pair_keys(self.Utrain, self.n_items, self.device),) + \
+                metrics.relevant_test_keys(self.Utest, self.n_items, self.device, self.config["med_score"])
+        u = self._idx(users)
+        idx, _ = ops.recommend_topk(self.X, self.Y, u, min(lim, self.n_items), M=self.n_items)
+        return metrics.mean_average_precision_device(idx, u, *self._eval_keys, self.n_items, lim)
+
+    def rmse(self, U=None):
+        """Root mean square error of the predictions over the stored entries of U (default: the test matrix), as
+        utils.py:58-59 on the reference's predict (ALS.py:359-362); computed on the device."""
+        import scipy.sparse as sps
+        U = self.Utest if U is None else sps.csr_matrix(U)
+        if U is None or U.nnz == 0:
+            return float("nan")
+        coo = U.tocoo()
+        pred = ops.predict_pairs(self.X, self.Y, self._idx(coo.row), self._idx(coo.col))
+        return metrics.rmse_device(pred, torch.as_tensor(coo.data, device=self.device))

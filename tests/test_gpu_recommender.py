@@ -275,6 +275,14 @@ def test_evaluate_matches_oracle_map(ra):
     oscore = als_ref.map_at_k(oidx, (te.indptr, te.indices, te.data), (tr.indptr, tr.indices, tr.data), users, 3.0, 200)
     assert abs(score - oscore) < 5e-4 and score > 0.9, (score, oscore)
     assert len(rec.eval_scores) == 3
+    # evaluate() runs on the device end to end; the host loop over the reference's compute_ap gives the same number
+    from recommender_amd import metrics
+    recs, _ = rec.recommend(users, k=200)
+    assert score == pytest.approx(metrics.mean_average_precision(recs, users, tr, te, 3.0, 200), rel=1e-12)
+    # rmse(): predictions over the stored test entries against their ratings (utils.py:58-59), on the device
+    tu, ti = te.nonzero()
+    want = metrics.rmse(rec.predict(tu, ti), np.asarray(te[tu, ti]).ravel())
+    assert rec.rmse() == pytest.approx(want, rel=1e-6)
 
 
 def test_c1_full_training_metrics_to_three_decimals(ra):
