@@ -496,7 +496,7 @@ def main():
 
         if plan and world == 1:
             # the eight-GPU configuration as one of its ranks runs it (long item rows, the whole user table)
-            prev = None
+            prev = None                     # drops the last reference to the c3 shards
             torch.cuda.empty_cache()
             state = None
             for (solver, cgs) in (("cholesky", 0), ("cg", args.cg_steps)):
