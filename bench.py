@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one ALS iteration (Gram(Y) -> X half-sweep -> Gram(X) -> Y half-sweep) over a
-synthetic MovieLens-25M-shaped implicit matrix, f=64 (BASELINE.json configs[1]).  With N
+synthetic MovieLens-25M-shaped implicit matrix, f=64 (the benchmark's one-GPU configuration).  With N
 GPUs the matrix is N user blocks of 162 541 users each over the same 59 047 items (weak
 scaling): rank r sweeps user block r and an nnz-balanced 1/N of the items, factors are
 all-gathered over RCCL after each half-sweep.  Inputs are resident in HBM before the timed
@@ -13,7 +13,7 @@ region.  Rank 0 prints ONE JSON line.
 
 Besides the headline fields that line carries an `also` list: the same measurement (fewer steps)
 at f=128 on the same matrix, exact and conjugate-gradient, and on `c3_shard_syn` - per GPU one
-eighth of the 10 M x 1 M, 1 B-entry, f=128 matrix of BASELINE.json configs[2]; with N GPUs the
+eighth of the 10 M x 1 M, 1 B-entry, f=128 matrix (the benchmark's eight-GPU configuration); with N GPUs the
 matrix is N such blocks with user shards cut by stored entries, so N=8 is that configuration.
 `--no-also` leaves them out; `--workload/--factors/--solver` move the headline itself.
 """
