@@ -60,6 +60,9 @@ def parse():
                     help="exact solver: how the per-row normal matrix is accumulated (see include/als_hip.h)")
     ap.add_argument("--row-kernel", default="auto", choices=["auto", "wave", "stream"],
                     help="64 < f <= 128: one wavefront per row, or one resident wavefront per SIMD streaming its rows")
+    ap.add_argument("--short-rows", default="auto", choices=["auto", "on", "off"],
+                    help="exact solver, 32 < f <= 128: rows with fewer stored entries than factors solved in their "
+                         "entry-space form (auto: where it pays, see recommender_amd/als.py::short_rows_pay)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="only the headline measurement")
     ap.add_argument("--also-steps", type=int, default=3)
@@ -191,7 +194,8 @@ class Ctx:
     pass
 
 
-def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel, steps, warmup, shards=None):
+def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel, steps, warmup, shards=None,
+            short_rows="auto"):
     """Builds (or reuses) the shards of `workload`, runs warmup + `steps` timed iterations and returns
     (result dict, shards, host init or None).  Every per-row kernel of every half-sweep is bracketed by
     events the library records on the launch stream (als_sweep_opts_t.tap_begin/tap_end)."""
@@ -222,7 +226,9 @@ def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel,
     csr_i = ops.DeviceCSR(Ut[0], Ut[1], Ut[2], (ib[rank + 1] - ib[rank], N), dev,
                           chunk_nnz=2048 * (1 if world == 1 else 4))
     eng = ALSEngine(csr_u, csr_i, X, Y, wl["lamb"], wl["alpha"], ub, ib, group, solver=solver,
-                    cg_steps=cg_steps, cg_form=cg_form)
+                    cg_steps=cg_steps, cg_form=cg_form, short_rows={"auto": "auto", "on": True, "off": False}[short_rows]
+                    if solver != "cg" else False)
+    short = dict(eng.short)
     cg = solver == "cg"
     lockstep = cg and (cg_form == "lock_step" or (cg_form == "auto" and f > 128))
 
@@ -296,12 +302,25 @@ def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel,
         "achieved": achieved, "launch_ms": {"user_sweep": ku, "item_sweep": ki},
         "bytes_per_launch": (bytes_u + bytes_i) / 2,
         "user_rows": csr_u.shape[0], "item_rows": csr_i.shape[0],
+        "short_rows": short_rows_note(short, csr_u, csr_i, f),
     }
     if not cg:
         fl = algorithmic_flops(csr_u.nnz, csr_u.shape[0], f) + algorithmic_flops(csr_i.nnz, csr_i.shape[0], f)
         res["mfma"] = mfma_view(fl / 2, (bytes_u + bytes_i) / 2, (ku + ki) / 2)
     del eng, csr_u, csr_i, X, Y
     return res, shards, (Xh, Yh, wl)
+
+
+def short_rows_note(short, csr_u, csr_i, f):
+    """Which half-sweeps solved their short rows in the entry-space form, and how many rows that was."""
+    from recommender_amd import ops
+    lim = ops.short_rows_max_entries(f)
+    nb = lim // 16
+    out = {"max_entries": lim}
+    for which, csr in (("users", csr_u), ("items", csr_i)):
+        n = int(csr.short_bounds[-1] - csr.short_bounds[nb]) if lim else 0
+        out[which] = {"entry_space_form": bool(short.get(which)), "rows_within_limit": n, "rows": csr.shape[0]}
+    return out
 
 
 def mfma_view(flops_per_launch, bytes_per_launch, launch_ms):
@@ -315,7 +334,8 @@ def mfma_view(flops_per_launch, bytes_per_launch, launch_ms):
             "peak_TFLOPs_f32_matrix": MFMA_F32_PEAK_TFLOPS, "frac": tf / MFMA_F32_PEAK_TFLOPS}
 
 
-def measure_rank_share(ctx, wl_name, solver, cg_steps, accumulate, row_kernel, steps, warmup, state=None):
+def measure_rank_share(ctx, wl_name, solver, cg_steps, accumulate, row_kernel, steps, warmup, state=None,
+                       short_rows="auto"):
     """What ONE rank of the `of_world`-GPU run of the full matrix executes per iteration, on one GPU: the user
     half-sweep over its n_users x n_items block, and the item half-sweep over its n_items / of_world items against ALL
     n_users * of_world users - rows of_world times longer than in the one-block matrix, gathered from the whole user
@@ -350,6 +370,16 @@ def measure_rank_share(ctx, wl_name, solver, cg_steps, accumulate, row_kernel, s
     cg = solver == "cg"
     base = dict(accumulate=accumulate, row_kernel=row_kernel)
     taps = {"users": [], "items": []}
+    # the decision of the W-rank run: totals over the whole matrix (this rank's user block is one of W alike; its
+    # item rows are one W-th of the items)
+    from recommender_amd.als import short_rows_pay
+    lim = ops.short_rows_max_entries(f)
+    short = {"users": False, "items": False}
+    if not cg and lim and short_rows != "off":
+        nsu = int(csr_u.short_bounds[-1] - csr_u.short_bounds[lim // 16]) * W
+        nsi = int(csr_i.short_bounds[-1] - csr_i.short_bounds[lim // 16]) * W
+        short = {"users": short_rows == "on" or short_rows_pay(nsu, N, M, f),
+                 "items": short_rows == "on" or short_rows_pay(nsi, M, N, f)}
 
     def sweep(csr, opp, cache, own, d, which, timed):
         opts = ops.sweep_opts(**base)
@@ -361,12 +391,16 @@ def measure_rank_share(ctx, wl_name, solver, cg_steps, accumulate, row_kernel, s
         if cg:
             ops.half_sweep_cg(csr, opp, cache, own, wl["alpha"], cg_steps, absdiff=d, info=info, opts=opts)
         else:
-            ops.half_sweep(csr, opp, cache, own, wl["alpha"], absdiff=d, info=info, opts=opts)
+            ops.half_sweep(csr, opp, cache, own, wl["alpha"], absdiff=d, info=info, opts=opts, short_rows=short[which])
 
     def step(timed):
         ops.gram(Y, wl["lamb"], out=cache_Y)
+        if short["users"]:
+            ops.whiten(Y, cache_Y, info=info)
         sweep(csr_u, Y, cache_Y, X[:nb], dX, "users", timed)
         ops.gram_partials(X, 0, nb)                 # this rank's share of the user table's Gram partials
+        if short["items"]:
+            ops.whiten(X, cache_X, info=info)
         sweep(csr_i, X, cache_X, Y[:mi], dY, "items", timed)
 
     for _ in range(warmup):
@@ -396,7 +430,8 @@ def measure_rank_share(ctx, wl_name, solver, cg_steps, accumulate, row_kernel, s
            "frac_per_launch": {"user_sweep": bu / (ku * 1e-3) / 1e9 / HBM_PEAK_GBS, "item_sweep": bi / (ki * 1e-3) / 1e9 / HBM_PEAK_GBS},
            "algorithmic_bytes_per_launch": (bu + bi) / 2,
            "traffic": pmc_traffic("%s_f%d" % (wl_name, f)) if not cg else None,
-           "rows_this_rank": {"user": csr_u.shape[0], "item": csr_i.shape[0]}}
+           "rows_this_rank": {"user": csr_u.shape[0], "item": csr_i.shape[0]},
+           "short_rows": short_rows_note(short, csr_u, csr_i, f)}
     if not cg:
         fl = algorithmic_flops(csr_u.nnz, csr_u.shape[0], f) + algorithmic_flops(csr_i.nnz, csr_i.shape[0], f)
         res["mfma"] = mfma_view(fl / 2, (bu + bi) / 2, (ku + ki) / 2)
@@ -448,7 +483,7 @@ def main():
         if world != 1:
             raise SystemExit("%s models one rank of a sharded run on one GPU: --gpus 1" % args.workload)
         r, _ = measure_rank_share(ctx, args.workload, args.solver, args.cg_steps, args.accumulate, args.row_kernel,
-                                  args.steps, args.warmup)
+                                  args.steps, args.warmup, short_rows=args.short_rows)
         print(json.dumps({"metric": "ALS nnz/sec (2*nnz per iteration; iterations/sec in iters_per_s)",
                           "value": r["nnz_per_s"], "unit": "nnz/s", "iters_per_s": 1e3 / r["ms_per_step"], "n_gpus": 1,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
@@ -458,10 +493,11 @@ def main():
                                        "frac": r["frac"], "frac_per_launch": r["frac_per_launch"], "traffic": None,
                                        "launch_ms": r["launch_ms"],
                                        "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
-                                       "mfma_view": r.get("mfma")}}), flush=True)
+                                       "mfma_view": r.get("mfma"), "short_rows": r["short_rows"]}}), flush=True)
         return
     head, shards, (Xh, Yh, wl) = measure(ctx, args.workload, args.factors, args.solver, args.cg_steps, args.cg_form,
-                                         args.accumulate, args.row_kernel, args.steps, args.warmup)
+                                         args.accumulate, args.row_kernel, args.steps, args.warmup,
+                                         short_rows=args.short_rows)
     f = head["f"]
     cg = head["solver"] == "cg"
 
@@ -478,7 +514,7 @@ def main():
         for (wname, ff, solver, sh, cgs) in plan:
             try:
                 r, prev, _ = measure(ctx, wname, ff, solver, cgs or args.cg_steps, "auto", args.accumulate, args.row_kernel,
-                                     args.also_steps, 1, shards=prev if sh == "prev" else sh)
+                                     args.also_steps, 1, shards=prev if sh == "prev" else sh, short_rows=args.short_rows)
                 also.append({"workload": r["workload"], "f": r["f"], "solver": r["solver"], "cg_steps": cgs or None,
                              "steps": r["steps"],
                              "nnz_per_s": r["value"], "ms_per_step": r["ms_per_step"], "launch_ms": r["launch_ms"],
@@ -486,7 +522,8 @@ def main():
                              "algorithmic_bytes_per_launch": r["bytes_per_launch"], "kernel": r["kernel"],
                              "traffic": pmc_traffic("%s_f%d%s" % (wname, r["f"], "" if solver != "cg" else
                                                                   "_cg" if cgs == args.cg_steps else "_cg%d" % cgs)),
-                             "rows_this_rank": {"user": r["user_rows"], "item": r["item_rows"]}})
+                             "rows_this_rank": {"user": r["user_rows"], "item": r["item_rows"]},
+                             "short_rows": r["short_rows"]})
                 if "mfma" in r:
                     also[-1]["mfma"] = r["mfma"]
             except Exception as exc:            # a failing extra point must not cost the headline line
@@ -502,7 +539,7 @@ def main():
             for (solver, cgs) in (("cholesky", 0), ("cg", args.cg_steps)):
                 try:
                     r, state = measure_rank_share(ctx, "c3_rank_syn", solver, cgs, args.accumulate, args.row_kernel,
-                                                  args.also_steps, 1, state)
+                                                  args.also_steps, 1, state, short_rows=args.short_rows)
                     also.append(r)
                 except Exception as exc:
                     also.append({"workload": "c3_rank_syn", "solver": solver, "error": repr(exc)})
@@ -539,6 +576,7 @@ def main():
         }
         if "mfma" in head:
             out["roofline"]["mfma_view"] = head["mfma"]
+        out["roofline"]["short_rows"] = head["short_rows"]
         if world > 1:
             out["distributed"] = {"backend": backend, "world_size": torch.distributed.get_world_size(), "ranks": ranks}
         if also:

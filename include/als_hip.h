@@ -70,18 +70,25 @@ int32_t als_abi_version(void);
  *       ALS_ROW_KERNEL_AUTO       the library's choice.
  *   tap_begin / tap_end  two hipEvent_t handles, or both NULL: recorded on `stream` immediately before
  *       the first and after the last per-row kernel of the call (benchmarks time the kernels with
- *       them; the final |delta| reduction lies outside). */
+ *       them; the final |delta| reduction lies outside).
+ *   whitened / ld_whitened / short_bounds  all NULL / 0: every row is solved as an f x f system.  Given (exact
+ *       half-sweep, 32 < f <= 128, f % 4 == 0): rows with at most min(f, 128) (f <= 64: 64) stored entries are
+ *       solved in their entry-space form, see "Short rows" below. */
 #define ALS_ACCUMULATE_DEFAULT 0
 #define ALS_ACCUMULATE_BF16X3 1
 #define ALS_ACCUMULATE_FP32 2
 #define ALS_ROW_KERNEL_AUTO 0
 #define ALS_ROW_KERNEL_WAVE 1
 #define ALS_ROW_KERNEL_STREAM 2
+#define ALS_SHORT_MAX_GROUPS 8      /* short rows: at most 16 * 8 = 128 entries */
 typedef struct {
     int32_t accumulate;
     int32_t row_kernel;
     void *tap_begin;
     void *tap_end;
+    const float *whitened;       /* [device] table of als_whiten_f32 for Yopp, or NULL (see "Short rows" below)  */
+    int64_t ld_whitened;         /* its leading dimension (>= 2 f, a multiple of 4)                              */
+    const int64_t *short_bounds; /* [host] the ALS_SHORT_MAX_GROUPS + 2 entries of als_plan_short_bounds         */
 } als_sweep_opts_t;
 
 /* ------------------------------------------------------------------------------------
@@ -181,6 +188,35 @@ int32_t als_half_sweep_csr_f32(const int64_t *rowptr, const int32_t *col, const 
                                const float *gram_tiles, int32_t f, float alpha, float *Xown, int64_t ldx,
                                double *absdiff_out, int32_t *info_out, const als_sweep_opts_t *opts,
                                void *workspace, size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Short rows - the same exact solve of als_run_regression (reclibwh/core/ALS.py:160-176; ALSRef, ALS.py:82-86)
+ * for rows with fewer stored entries than factors, in the algebraically equal "entry space" form.  With
+ * G = Y^T Y + lamb I = R^T R (Cholesky) and L entries (y_e, r_e), w_e = alpha r_e:
+ *     x = G^-1 sum_e sqrt(w_e) t_e y_e,   (I + V V^T) t = (1 + w) / sqrt(w),   V_e = sqrt(w_e) y_e R^-1
+ * - an L x L symmetric positive definite system (every eigenvalue >= 1) instead of the f x f one.  No reference
+ * counterpart as code: the reference inverts the f x f matrix for every row whatever its length; results agree with
+ * it to float32 rounding (the form is the better conditioned of the two).
+ *
+ * als_whiten_f32 prepares, once per half-sweep, the table WZ [n, ldw] of the fixed factor:
+ * columns [0, f) = Y R^-1, columns [f, 2 f) = Y G^-1 (R and the inverses in float64 from `gram`, the float32
+ * gram_out of als_gram_f32, plus lamb; then one GEMM on the matrix cores, float32 accuracy).  32 < f <= 128,
+ * f % 4 == 0, ldy and ldw multiples of 4, 16-byte aligned pointers, ldw >= 2 f.  info_out (optional) is incremented
+ * if gram + lamb I is not positive definite.  Workspace: als_whiten_workspace_bytes(f).
+ *
+ * als_plan_short_bounds (host) returns, for the plan als_plan_fill builds from the same arguments,
+ * bounds_out[j], j = 0..ALS_SHORT_MAX_GROUPS: the index in the item list of the first whole-row item with at most
+ * 16 j stored entries (whole rows are listed by entry count, descending), and bounds_out[ALS_SHORT_MAX_GROUPS + 1] =
+ * n_items.  als_short_rows_max_groups(f): the largest j the kernels use for this f (0: no short-row form).
+ * Pass table, leading dimension and bounds in als_sweep_opts_t to als_half_sweep_csr_f32 (or its _static_ variant):
+ * rows of at most 16 * max_groups entries then take this form, all others the f x f form; a row's result depends on
+ * the row and the inputs only, never on the launch shape, so sweeps stay reproducible and independent of sharding.
+ * ------------------------------------------------------------------------------------ */
+int32_t als_short_rows_max_groups(int32_t f);
+int32_t als_plan_short_bounds(const int64_t *rowptr_host, int64_t n_rows, int32_t chunk_nnz, int64_t *bounds_out);
+size_t als_whiten_workspace_bytes(int32_t f);
+int32_t als_whiten_f32(const float *gram, float lamb, int32_t f, const float *Y, int64_t n, int64_t ldy, float *WZ,
+                       int64_t ldw, int32_t *info_out, void *workspace, size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Half-sweep for callers that cannot allocate device memory.  No counterpart in the reference: it is

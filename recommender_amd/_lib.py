@@ -22,6 +22,7 @@ GRAM_SUPER_ROWS = 65536
 MAX_FACTORS = 256
 MAX_FACTORS_EXACT = 128
 GRAM_WIDE_CHUNK_ROWS = 4096
+SHORT_MAX_GROUPS = 8
 ACCUMULATE_MODES = {"default": 0, "bf16x3": 1, "fp32": 2}
 ROW_KERNELS = {"auto": 0, "wave": 1, "stream": 2}
 CG_FORMS = {"auto": 0, "lock_step": 1, "matrix": 2}
@@ -51,6 +52,10 @@ SIGNATURES = {
     "als_half_sweep_cg_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32,
                                       c_vp, c_i64, c_i64, c_vp, c_vp, c_f32, c_i32, c_f32, c_i32, c_i32, c_vp, c_i64, c_vp,
                                       c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "als_short_rows_max_groups": (c_i32, [c_i32]),
+    "als_plan_short_bounds": (c_i32, [c_vp, c_i64, c_i32, c_vp]),
+    "als_whiten_workspace_bytes": (c_sz, [c_i32]),
+    "als_whiten_f32": (c_i32, [c_vp, c_f32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
     "als_static_scratch_bytes": (c_sz, []),
     "als_static_scratch_init": (c_i32, []),
     "als_half_sweep_csr_static_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32,
@@ -63,7 +68,8 @@ SIGNATURES = {
 
 class SweepOpts(ctypes.Structure):
     """als_sweep_opts_t of include/als_hip.h."""
-    _fields_ = [("accumulate", c_i32), ("row_kernel", c_i32), ("tap_begin", c_vp), ("tap_end", c_vp)]
+    _fields_ = [("accumulate", c_i32), ("row_kernel", c_i32), ("tap_begin", c_vp), ("tap_end", c_vp),
+                ("whitened", c_vp), ("ld_whitened", c_i64), ("short_bounds", c_vp)]
 
 
 class AlsHipError(RuntimeError):

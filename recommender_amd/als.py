@@ -78,16 +78,29 @@ def als_update_cache(Y, lamb, cache=None, group=None, backend=ops):
 
 
 def run_als_epoch(csr, X, Y, cache, alpha, absdiff=None, info=None, backend=ops, cg_steps=0, cg_form="auto",
-                  opts=None):
+                  opts=None, short_rows=False):
     """One half-sweep over the rows of `csr`: re-solves those rows of X in place against the
     fixed Y and its cache (ALS.py:201-233).  Returns the device scalar sum|X_old - X_new|
     (float64); the reference's return value is that divided by n_rows * f.
     cg_steps > 0: that many conjugate-gradient steps per row instead of the exact solve.
-    opts: ops.sweep_opts(...) - per-call kernel options (accumulate mode, timing taps)."""
+    opts: ops.sweep_opts(...) - per-call kernel options (accumulate mode, timing taps).
+    short_rows: rows with fewer entries than factors are solved in their entry-space form from cache.whitened
+    (ops.whiten; exact solve only)."""
     if cg_steps:
         return backend.half_sweep_cg(csr, Y, cache, X, alpha, cg_steps, absdiff=absdiff, info=info, form=cg_form,
                                      opts=opts)
+    if short_rows:
+        return backend.half_sweep(csr, Y, cache, X, alpha, absdiff=absdiff, info=info, opts=opts, short_rows=True)
     return backend.half_sweep(csr, Y, cache, X, alpha, absdiff=absdiff, info=info, opts=opts)
+
+
+def short_rows_pay(n_short, n_rows, n_opp, f):
+    """Whether a half-sweep should solve its short rows (at most ops.short_rows_max_entries(f) entries) in their
+    entry-space form.  The form needs the whitened table of the fixed factor - one GEMM over its n_opp rows per
+    half-sweep - so it pays when enough rows use it: at least a tenth of the rows and one for every 8 rows whitened.
+    n_opp >= 16 f keeps the Gram that is factored well away from rank deficiency.  All arguments are totals over the
+    whole matrix, so every rank of a sharded run decides alike and the factors do not depend on the sharding."""
+    return bool(ops.short_rows_max_entries(f) > 0 and n_opp >= 16 * f and n_short * 10 >= n_rows and n_short * 8 >= n_opp)
 
 
 def _host_staged(T, group):
@@ -200,7 +213,7 @@ class ALSEngine:
     """
 
     def __init__(self, csr_users, csr_items, X, Y, lamb, alpha, user_bounds=None, item_bounds=None, group=None,
-                 backend=ops, overlap_chunks=None, solver="auto", cg_steps=10, cg_form="auto"):
+                 backend=ops, overlap_chunks=None, solver="auto", cg_steps=10, cg_form="auto", short_rows="auto"):
         self.group = group
         self.backend = backend      # the HIP operators; tests inject a CPU stand-in to exercise the sharding logic
         self.world = torch.distributed.get_world_size(group) if group is not None else 1
@@ -233,6 +246,9 @@ class ALSEngine:
         if solver == "cg" and self.cg_steps < 1:
             raise ValueError("cg_steps must be >= 1")
         self.cg_form = cg_form
+        # short_rows: "auto" (short_rows_pay on the matrix's totals), True or False - whether the user / item
+        # half-sweep solves rows with fewer entries than factors in their entry-space form (exact solver only)
+        self.short = self._decide_short_rows(short_rows)
         self.sweep_opts = None         # callable("users" | "items") -> ops.sweep_opts(...) for that launch, or None
         self.cache_Y = backend.GramCache(self.f, lamb, X.device)
         self.cache_X = backend.GramCache(self.f, lamb, X.device)
@@ -249,6 +265,26 @@ class ALSEngine:
         self.overlap_chunks = max(1, int(overlap_chunks))      # the same on every rank
         self._user_parts = None
         self._side = None
+
+    def _decide_short_rows(self, mode):
+        off = {"users": False, "items": False}
+        if mode not in ("auto", True, False):
+            raise ValueError("short_rows must be 'auto', True or False")
+        lim = ops.short_rows_max_entries(self.f) if self.backend is ops else 0
+        if mode is False or self.solver != "cholesky" or lim == 0 or self.f % 4 or not self.X.is_cuda:
+            if mode is True:
+                raise ValueError("short_rows=True needs the exact solver, 32 < f <= 128 and f a multiple of 4")
+            return off
+        if mode is True:
+            return {"users": True, "items": True}
+        nb = lim // 16
+        mine = [int(c.short_bounds[-1] - c.short_bounds[nb]) for c in (self.csr_users, self.csr_items)]
+        if self.world > 1:          # totals over the ranks: every rank takes the same decision
+            t = torch.tensor(mine, dtype=torch.int64, device="cpu" if _host_staged(self.X, self.group) else self.X.device)
+            torch.distributed.all_reduce(t, group=self.group)
+            mine = [int(v) for v in t.cpu().tolist()]
+        return {"users": short_rows_pay(mine[0], self.n_users, self.Y.shape[0], self.f),
+                "items": short_rows_pay(mine[1], self.n_items, self.X.shape[0], self.f)}
 
     def _parts(self):
         """[(row0, row1, csr chunk or None if empty, |delta| buffer)], chunk c of this rank's user shard."""
@@ -276,7 +312,8 @@ class ALSEngine:
         for c, (r0, r1, csr, dbuf) in enumerate(parts):
             if csr is not None:
                 run_als_epoch(csr, self.X[u0 + r0:u0 + r1], self.Y, self.cache_Y, self.alpha, dbuf, self.info,
-                              self.backend, self.cg_steps, self.cg_form, self.sweep_opts("users") if self.sweep_opts else None)
+                              self.backend, self.cg_steps, self.cg_form, self.sweep_opts("users") if self.sweep_opts else None,
+                              self.short["users"])
             else:
                 dbuf.zero_()
             if not chunked:
@@ -304,11 +341,16 @@ class ALSEngine:
     def step(self):
         i0, i1 = self.item_bounds[self.rank], self.item_bounds[self.rank + 1]
         als_update_cache(self.Y, self.lamb, self.cache_Y, self.group, self.backend)
+        if self.short["users"]:
+            self.backend.whiten(self.Y, self.cache_Y, info=self.info)
         self._sweep_users()
         als_update_cache(self.X, self.lamb, self.cache_X, self.group, self.backend)
+        if self.short["items"]:
+            self.backend.whiten(self.X, self.cache_X, info=self.info)
         if i1 > i0:
             run_als_epoch(self.csr_items, self.Y[i0:i1], self.X, self.cache_X, self.alpha, self._dY, self.info,
-                          self.backend, self.cg_steps, self.cg_form, self.sweep_opts("items") if self.sweep_opts else None)
+                          self.backend, self.cg_steps, self.cg_form, self.sweep_opts("items") if self.sweep_opts else None,
+                          self.short["items"])
         if self.world > 1:
             _all_gather_rows(self.Y[: self.n_items], self.item_bounds, self.rank, self.group)
 

@@ -38,6 +38,10 @@ int32_t als_half_sweep_tiles_(const int64_t *rowptr, const int32_t *col, const f
                               float alpha, int32_t cg_steps, float *Xown, int64_t ldx, double *absdiff_out,
                               int32_t *info_out, const als_sweep_opts_t *opts, void *workspace, size_t ws_bytes,
                               void *stream);
+// short rows in their entry-space form, als_short_rows.hip
+int32_t als_short_rows_launch_(const int32_t *col, const float *val, const int64_t *row_ids, const als_item_t *items,
+                               const int64_t *bounds, int32_t nb_max, const float *WZ, int64_t ldw, int32_t f, float alpha,
+                               float *Xown, int64_t ldx, float *rowdiff, int32_t *info, hipStream_t st);
 // wide Gram (128 < f <= 256), als_cg.hip
 size_t als_gram_wide_tiles_bytes_(int f);
 size_t als_gram_wide_workspace_bytes_(int64_t n, int f);
@@ -89,27 +93,7 @@ int32_t static_scratch_ptr(void **out) {
     return ALS_OK;
 }
 
-// ----------------------------------------------------------------------------- geometry
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-template <int VW>
-struct Geo {
-    static constexpr int FPAD = 16 * VW;               // padded factor count
-    static constexpr int NT = VW * (VW + 1) / 2;       // symmetric 16x16 tiles
-    static constexpr int TQ = NT * 4;                  // tile floats per lane
-    static constexpr int PQ = NT * 4 + VW;             // floats per lane of a stored partial (tiles + b)
-    static constexpr int TRI = FPAD * (FPAD + 1) / 2;  // packed lower triangle
-};
-
-__host__ __device__ constexpr int tile_index(int ta, int tb, int VW) { return ta * VW - ta * (ta - 1) / 2 + (tb - ta); }
-
-// factor index held by lane j (0..15) of a group in its register t (0..VW-1)
-template <int VW>
-__host__ __device__ __forceinline__ constexpr int fidx(int j, int t) {
-    if constexpr (VW <= 4) return VW * j + t;
-    else return (t < 4) ? 4 * j + t : 64 + 4 * j + (t - 4);
-}
+#include "als_tiles.inc"
 
 #ifndef ALS_SWEEP_WAVES_F128
 #define ALS_SWEEP_WAVES_F128 1  // 64 < f <= 128: 144 accumulator registers + the stages need > 256 registers
@@ -222,19 +206,12 @@ __device__ __forceinline__ void compute(const Stage<VW> &st, f32x4 (&acc)[Geo<VW
 // No data movement is needed: lane (g, j) holds, for its 4 (or 8) factor indices, the entries
 // 4q + g (q = 0..7) of a 32-entry block - exactly the 8 k-slots a lane owns in the A and in the B
 // fragment (slot 8g + q <-> entry 4q + g, the same permutation for both operands).
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int VW>
 struct SplitOps {
     unsigned H[VW][4], M[VW][4], L[VW][4];   // fragment register r holds k-slots 2r (low half) and 2r + 1
 };
 
-// low half <- high 16 bits of a, high half <- high 16 bits of b (two truncated bf16)
-__device__ __forceinline__ unsigned pack_trunc(const float a, const float b) {
-    return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
-}
-__device__ __forceinline__ float trunc_bf16(const float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
 
 // Pieces of the GS k-steps of one stage into fragment registers [QB/2, QB/2 + GS/2); also bacc.
 // st.w holds sqrt(alpha r) here.
@@ -290,10 +267,6 @@ __device__ __forceinline__ void split_zero(const int QB, SplitOps<VW> &o) {
     for (int p = 0; p < GS / 2; ++p)
 #pragma unroll
         for (int t = 0; t < VW; ++t) o.H[t][QB / 2 + p] = o.M[t][QB / 2 + p] = o.L[t][QB / 2 + p] = 0u;
-}
-__device__ __forceinline__ f32x4 mfma_bf16(const unsigned (&a)[4], const unsigned (&b)[4], const f32x4 &c) {
-    const u32x4 av{a[0], a[1], a[2], a[3]}, bv{b[0], b[1], b[2], b[3]};
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
 }
 template <int VW>
 __device__ __forceinline__ void split_mfma_pass(const unsigned (&A)[VW][4], const unsigned (&B)[VW][4],
@@ -405,378 +378,6 @@ __device__ __forceinline__ void reduce_b(float (&bacc)[VW]) {
         bacc[t] += __shfl_xor(bacc[t], 16);
         bacc[t] += __shfl_xor(bacc[t], 32);
     }
-}
-
-// ----------------------------------------------------------------------------- solve
-__device__ __forceinline__ float readlane_f(const float x, const int l) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
-}
-
-// ----------------------------------------------------------------------------- blocked solve
-// Solve in the accumulator layout, without LDS and without moving the matrix.
-//
-// The symmetric matrix sits in the wave as VW*(VW+1)/2 tiles of 16 x 16 (tile (ta, tb), ta <= tb):
-// lane (g, c) = (lane>>4, lane&15), register r holds element (row 4g+r, column c).  In the index
-// order p = 16*t + i (a permutation of the factor indices, harmless for an SPD system) this is a
-// VW x VW grid of contiguous blocks, so a right-looking block Cholesky A = U^T U applies:
-//   for kb:  X    = U_kk^{-1}                      (16 steps of elimination on the diagonal tile)
-//            U_kj = X^T A_kj        (jb > kb)       4 MFMAs per tile
-//            A_ij -= U_ki^T U_kj    (kb < ib <= jb) 4 MFMAs per tile
-// A product X^T Z of two tiles needs no data movement: register r of X and of Z are exactly the A
-// and B operands of v_mfma_f32_16x16x4_f32 for the 4 rows {4g+r}; the 4 registers cover all rows.
-// Vectors are kept "column indexed" (element c of a block in lane c, replicated over the 4 lane
-// groups) or "row indexed" (element 4g+r in register r of lane group g).
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(const float x) {
-    // bound_ctrl = true: no lane is out of bounds for the controls used here, and it spares the
-    // compiler a zero-initialisation of the destination before every v_mov_b32_dpp
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
-}
-// sum over the 16 lanes of a row, result in every lane of the row (fixed butterfly order)
-__device__ __forceinline__ float row_sum16(float x) {
-    x += dpp_f<0xB1>(x);   // quad_perm [1,0,3,2]
-    x += dpp_f<0x4E>(x);   // quad_perm [2,3,0,1]
-    x += dpp_f<0x141>(x);  // row_half_mirror
-    x += dpp_f<0x140>(x);  // row_mirror
-    return x;
-}
-// sum over the 4 lane groups, result in every group
-__device__ __forceinline__ float grp_sum4(float x) {
-    x += __shfl_xor(x, 16);
-    x += __shfl_xor(x, 32);
-    return x;
-}
-// out (+)= X^T Z  (NEG: out -= X^T Z)
-template <bool NEG>
-__device__ __forceinline__ void tile_xtz(const f32x4 &X, const f32x4 &Z, f32x4 &out) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) out = __builtin_amdgcn_mfma_f32_16x16x4f32(NEG ? -X[r] : X[r], Z[r], out, 0, 0, 0);
-}
-// column indexed -> row indexed
-__device__ __forceinline__ f32x4 vec_col_to_row(const float vcol, const int lane) {
-    const int g = lane >> 4;
-    f32x4 o;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = __shfl(vcol, 20 * g + r);   // lane 16g + (4g + r)
-    return o;
-}
-// row indexed -> column indexed
-__device__ __forceinline__ float vec_row_to_col(const f32x4 &vrow, const int lane) {
-    const int c = lane & 15;
-    const float lo = (c & 1) ? vrow[1] : vrow[0], hi = (c & 1) ? vrow[3] : vrow[2];
-    const float tmp = (c & 2) ? hi : lo;
-    return __shfl(tmp, 16 * (c >> 2) + c);
-}
-// out[c] = sum_k X[k][c] v[k], v row indexed, out column indexed
-__device__ __forceinline__ float tile_xt_v(const f32x4 &X, const f32x4 &vrow) {
-    float p = X[0] * vrow[0];
-#pragma unroll
-    for (int r = 1; r < 4; ++r) p = fmaf(X[r], vrow[r], p);
-    return grp_sum4(p);
-}
-// out[k] = sum_c X[k][c] v[c], v column indexed, out row indexed
-__device__ __forceinline__ f32x4 tile_x_v(const f32x4 &X, const float vcol) {
-    f32x4 o;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = row_sum16(X[r] * vcol);
-    return o;
-}
-
-// d += row_newbcast:K(d) * nv as ONE instruction (v_fmac_f32 with a DPP source).  hipcc keeps a
-// v_mov_b32_dpp + v_fmac_f32 pair for the builtin form, and half of the solve's vector instructions
-// are these.  The compiler does not see inside an asm statement, so the DPP read hazard (a VGPR
-// written by a vector instruction may be read through DPP two wait states later at the earliest)
-// is handled here: the statements are volatile, hence stay in program order, and every register
-// is touched at most once per elimination step (4 to 8 statements apart); GUARD adds the wait states for the
-// first statement on each register after step 0, whose source was last written by compiler-scheduled code
-// that the scheduler may place directly in front of it (step 1 for most, steps 2 and 3 for N's registers 2
-// and 3, which steps 1 and 2 leave alone).  tools/check_dpp_hazard.py verifies the generated code.
-#define ALS_FMAC_BCAST_CASE(n)                                                                            \
-    if constexpr (K == n) {                                                                               \
-        if constexpr (GUARD)                                                                              \
-            asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 row_newbcast:" #n " row_mask:0xf bank_mask:0xf" \
-                         : "+v"(d) : "v"(nv));                                                            \
-        else                                                                                              \
-            asm volatile("v_fmac_f32_dpp %0, %0, %1 row_newbcast:" #n " row_mask:0xf bank_mask:0xf"       \
-                         : "+v"(d) : "v"(nv));                                                            \
-    }
-template <int K, bool GUARD>
-__device__ __forceinline__ void fmac_bcast(float &d, const float nv) {
-    ALS_FMAC_BCAST_CASE(0) ALS_FMAC_BCAST_CASE(1) ALS_FMAC_BCAST_CASE(2) ALS_FMAC_BCAST_CASE(3)
-    ALS_FMAC_BCAST_CASE(4) ALS_FMAC_BCAST_CASE(5) ALS_FMAC_BCAST_CASE(6) ALS_FMAC_BCAST_CASE(7)
-    ALS_FMAC_BCAST_CASE(8) ALS_FMAC_BCAST_CASE(9) ALS_FMAC_BCAST_CASE(10) ALS_FMAC_BCAST_CASE(11)
-    ALS_FMAC_BCAST_CASE(12) ALS_FMAC_BCAST_CASE(13) ALS_FMAC_BCAST_CASE(14) ALS_FMAC_BCAST_CASE(15)
-}
-#undef ALS_FMAC_BCAST_CASE
-
-// One elimination step on a diagonal tile D (pivot K) and on N, which accumulates the inverse of
-// the unit upper factor by the mirrored column operations.
-template <int K>
-__device__ __forceinline__ void diag_step(f32x4 &D, f32x4 &N, const int c) {
-    constexpr int reg = K & 3, src = 16 * (K >> 2);
-    const float d = readlane_f(D[reg], src + K);
-    float rd = __builtin_amdgcn_rcpf(d);
-    rd = rd * fmaf(-d, rd, 2.0f);                        // one Newton step on the reciprocal
-    const float rowk = __shfl(D[reg], src + c);          // row K of D in every lane group
-    const float nv = (c > K) ? -(rowk * rd) : 0.f;
-    if constexpr (K == 0) {   // sources come straight from compiler-scheduled code (MFMA results, N's init)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            D[r] = fmaf(dpp_f<0x150 + K>(D[r]), nv, D[r]);   // row_newbcast:K = D[4g+r][K]
-            N[r] = fmaf(dpp_f<0x150 + K>(N[r]), nv, N[r]);
-        }
-    } else {
-        // register r holds rows r, 4+r, 8+r, 12+r.  Rows <= K of D are never read again (only the
-        // pivots are, and row K's is final), and column K of N is still zero below row K: registers
-        // that hold only such rows are left alone.
-        float d0 = D[0], d1 = D[1], d2 = D[2], d3 = D[3], n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3];
-        if constexpr (K < 12) fmac_bcast<K, K == 1>(d0, nv);
-        if constexpr (K < 13) fmac_bcast<K, K == 1>(d1, nv);
-        if constexpr (K < 14) fmac_bcast<K, K == 1>(d2, nv);
-        if constexpr (K < 15) fmac_bcast<K, K == 1>(d3, nv);
-        fmac_bcast<K, K == 1>(n0, nv);
-        fmac_bcast<K, K == 1>(n1, nv);
-        if constexpr (K >= 2) fmac_bcast<K, K == 2>(n2, nv);   // n2, n3: step 0's result is still their last write
-        if constexpr (K >= 3) fmac_bcast<K, K == 3>(n3, nv);
-        D = f32x4{d0, d1, d2, d3};
-        N = f32x4{n0, n1, n2, n3};
-    }
-}
-struct NoFiller {
-    template <typename K> __device__ __forceinline__ void operator()(K) const {}
-};
-template <typename F, int... Ks>
-__device__ __forceinline__ void diag_steps(f32x4 &D, f32x4 &N, const int c, F &filler, std::integer_sequence<int, Ks...>) {
-    ((filler(std::integral_constant<int, Ks>{}), diag_step<Ks>(D, N, c)), ...);
-}
-// X = U_d^{-1} for the SPD tile D (U_d its upper Cholesky factor); ok = all pivots positive.  filler(K) is called in
-// front of elimination step K: independent matrix-pipe work that is issued beside the step's chain of dependent
-// vector instructions.
-template <typename F = NoFiller>
-__device__ __forceinline__ f32x4 diag_inverse_factor(f32x4 D, const int lane, bool &ok, F filler = F{}) {
-    const int g = lane >> 4, c = lane & 15;
-    f32x4 N;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) N[r] = (4 * g + r == c) ? 1.f : 0.f;
-    diag_steps(D, N, c, filler, std::make_integer_sequence<int, 16>{});
-    // pivot d_c is still at lane (c>>2, c), register c&3 (column c is never touched after step c)
-    const float lo = (c & 1) ? D[1] : D[0], hi = (c & 1) ? D[3] : D[2];
-    const float dvec = __shfl((c & 2) ? hi : lo, 16 * (c >> 2) + c);
-    ok = ok && !__any(!(dvec > 0.f));
-    float sc = __builtin_amdgcn_rsqf(dvec);
-    sc = sc * fmaf(-0.5f * dvec * sc, sc, 1.5f);         // one Newton step on 1/sqrt(d)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) N[r] *= sc;
-    return N;
-}
-
-// Back substitution on the factored tiles (diagonal slots hold X = U_kk^{-1}): the per-lane products of a block row
-// are added up first, one lane reduction per block.
-template <int VW>
-__device__ __forceinline__ void back_substitute(const f32x4 (&T)[Geo<VW>::NT], const float (&zcol)[VW], float (&x)[VW],
-                                                const int lane) {
-#ifdef ALS_ABLATE_NO_BACKSUB
-#pragma unroll
-    for (int kb = 0; kb < VW; ++kb) x[kb] = zcol[kb] + T[tile_index(kb, VW - 1, VW)][0];      // timing-only: wrong values
-    return;
-#endif
-#pragma unroll
-    for (int kb = VW - 1; kb >= 0; --kb) {
-        f32x4 part = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int jb = kb + 1; jb < VW; ++jb) part += T[tile_index(kb, jb, VW)] * x[jb];
-        f32x4 acc = vec_col_to_row(zcol[kb], lane);
-        if (kb + 1 < VW) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] -= row_sum16(part[r]);
-        }
-        x[kb] = vec_row_to_col(tile_x_v(T[tile_index(kb, kb, VW)], vec_row_to_col(acc, lane)), lane);
-    }
-}
-
-// Solves T x = b.  T: the VW*(VW+1)/2 tiles (destroyed), b: column-indexed right-hand side per
-// block (destroyed).  x: column-indexed solution per block.  Returns false if a pivot was <= 0.
-template <int VW>
-__device__ __forceinline__ bool blocked_solve(f32x4 (&T)[Geo<VW>::NT], float (&b)[VW], float (&x)[VW], const int lane) {
-    float zcol[VW];
-    // forward substitution: b_ib -= sum_kb U_kb,ib^T z_kb.  The per-lane products of all block steps are
-    // added up first and reduced over the lane groups once, when block ib's turn comes.
-    float pend[VW];
-#pragma unroll
-    for (int t = 0; t < VW; ++t) pend[t] = 0.f;
-    bool ok = true;
-#pragma unroll
-    for (int kb = 0; kb < VW; ++kb) {
-        // the diagonal tile is dead once factored: its slot keeps X = U_kk^{-1} for the back substitution
-#ifdef ALS_ABLATE_NO_DIAG
-        const f32x4 X = T[tile_index(kb, kb, VW)];      // timing-only: wrong values
-#else
-        const f32x4 X = diag_inverse_factor(T[tile_index(kb, kb, VW)], lane, ok);
-#endif
-        T[tile_index(kb, kb, VW)] = X;
-#pragma unroll
-        for (int jb = kb + 1; jb < VW; ++jb) {
-            f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f};
-#ifdef ALS_ABLATE_NO_PANEL
-            u = X * T[tile_index(kb, jb, VW)];            // timing-only: wrong values
-#else
-            tile_xtz<false>(X, T[tile_index(kb, jb, VW)], u);
-#endif
-            T[tile_index(kb, jb, VW)] = u;
-        }
-        if (kb > 0) b[kb] -= grp_sum4(pend[kb]);
-        zcol[kb] = tile_xt_v(X, vec_col_to_row(b[kb], lane));          // z_kb = U_kk^{-T} b_kb
-        const f32x4 zrow = vec_col_to_row(zcol[kb], lane);
-#pragma unroll
-        for (int ib = kb + 1; ib < VW; ++ib) {
-            const f32x4 Ui = T[tile_index(kb, ib, VW)];
-            const f32x4 nUi = -Ui;
-#pragma unroll
-            for (int jb = ib; jb < VW; ++jb) {
-#ifdef ALS_ABLATE_NO_TRAILING
-                T[tile_index(ib, jb, VW)] += nUi * T[tile_index(kb, jb, VW)];   // timing-only: wrong values
-#else
-                tile_xtz<false>(nUi, T[tile_index(kb, jb, VW)], T[tile_index(ib, jb, VW)]);
-#endif
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pend[ib] = fmaf(Ui[r], zrow[r], pend[ib]);
-        }
-        __builtin_amdgcn_sched_barrier(0);   // block steps stay in order: bounds the live ranges
-    }
-    back_substitute<VW>(T, zcol, x, lane);
-    return ok;
-}
-
-// ----------------------------------------------------------------------------- blocked solve, block products on the bf16 pipe
-// The same right-looking block Cholesky with the panel solves U_kj = X^T A_kj and the trailing updates
-// A_ij -= U_ki^T U_kj as products of three-way bf16 splits (the accumulate's scheme: 6 of the 9 piece products,
-// float32 accumulation) on v_mfma_f32_16x16x16_bf16: 6 x 8 matrix-pipe cycles per tile product against 4 x 32 of the
-// float32 form - and, unlike the float32 form, running beside vector instructions.  A tile in accumulator layout is
-// again an operand as it lies: lane (g, c) holds rows 4g..4g+3 of column c, exactly the 4 k-slots a lane owns in the
-// A and in the B fragment (k = row).  The trailing products of block step k - 1 - all but the one into the next
-// diagonal tile - are issued in 16 portions in front of the 16 elimination steps of diagonal tile k, whose chain of
-// dependent vector instructions leaves the matrix pipe idle otherwise.
-typedef short bf16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-struct TilePieces { unsigned p[3][2]; };      // [0] hi, [1] mid, [2] lo; register q holds rows 4g + 2q, 4g + 2q + 1
-__device__ __forceinline__ TilePieces split_tile(const f32x4 &t) {
-    TilePieces o;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const float x0 = t[2 * q], x1 = t[2 * q + 1];
-        const float r0 = x0 - trunc_bf16(x0), r1 = x1 - trunc_bf16(x1);
-        const float l0 = r0 - trunc_bf16(r0), l1 = r1 - trunc_bf16(r1);
-        o.p[0][q] = pack_trunc(x0, x1);
-        o.p[1][q] = pack_trunc(r0, r1);
-        o.p[2][q] = pack_trunc(l0, l1);
-    }
-    return o;
-}
-__device__ __forceinline__ TilePieces negated(const TilePieces &a) {
-    TilePieces o;
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) o.p[k][q] = a.p[k][q] ^ 0x80008000u;
-    return o;
-}
-__device__ __forceinline__ f32x4 mfma_bf16_k16(const unsigned (&a)[2], const unsigned (&b)[2], const f32x4 &c) {
-    const u32x2 av{a[0], a[1]}, bv{b[0], b[1]};
-    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf16x4, av), __builtin_bit_cast(bf16x4, bv), c, 0, 0, 0);
-}
-// piece product pr of out += X^T Z (smallest first: lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi)
-template <int PR>
-__device__ __forceinline__ void piece_product(const TilePieces &X, const TilePieces &Z, f32x4 &out) {
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-    out = mfma_bf16_k16(X.p[PA[PR]], Z.p[PB[PR]], out);
-}
-__device__ __forceinline__ void tile_xtz_pieces(const TilePieces &X, const TilePieces &Z, f32x4 &out) {
-    piece_product<0>(X, Z, out); piece_product<1>(X, Z, out); piece_product<2>(X, Z, out);
-    piece_product<3>(X, Z, out); piece_product<4>(X, Z, out); piece_product<5>(X, Z, out);
-}
-// Portion K (of 16) of the trailing products of block step KB - 1 that were left pending: A_ij -= U_i^T U_j for
-// KB <= ib <= jb < VW except (KB, KB); piece product outermost, so consecutive MFMAs go to different tiles.
-template <int VW, int KB, int K, int PR>
-__device__ __forceinline__ void pending_piece(f32x4 (&T)[Geo<VW>::NT], const TilePieces (&U)[VW], const TilePieces (&nU)[VW],
-                                              int &m) {
-    constexpr int n = VW - KB, TOTAL = 6 * (n * (n + 1) / 2 - 1), PER = (TOTAL + 15) / 16;
-#pragma unroll
-    for (int ib = KB; ib < VW; ++ib)
-#pragma unroll
-        for (int jb = ib; jb < VW; ++jb) {
-            if (ib == KB && jb == KB) continue;
-            if (m >= K * PER && m < (K + 1) * PER) piece_product<PR>(nU[ib], U[jb], T[tile_index(ib, jb, VW)]);
-            ++m;
-        }
-}
-template <int VW, int KB, int K>
-__device__ __forceinline__ void pending_products(f32x4 (&T)[Geo<VW>::NT], const TilePieces (&U)[VW], const TilePieces (&nU)[VW]) {
-    int m = 0;
-    pending_piece<VW, KB, K, 0>(T, U, nU, m); pending_piece<VW, KB, K, 1>(T, U, nU, m);
-    pending_piece<VW, KB, K, 2>(T, U, nU, m); pending_piece<VW, KB, K, 3>(T, U, nU, m);
-    pending_piece<VW, KB, K, 4>(T, U, nU, m); pending_piece<VW, KB, K, 5>(T, U, nU, m);
-}
-template <int VW, int KB>
-struct PendingFiller {
-    f32x4 (&T)[Geo<VW>::NT];
-    const TilePieces (&U)[VW];
-    const TilePieces (&nU)[VW];
-    template <typename Kc> __device__ __forceinline__ void operator()(Kc) const {
-        if constexpr (KB > 0 && KB + 1 < VW) {
-            pending_products<VW, KB, Kc::value>(T, U, nU);
-            __builtin_amdgcn_sched_barrier(0);      // a portion stays with its elimination step
-        }
-    }
-};
-// block step KB: U / nU hold the pieces of block row KB - 1 on entry, of block row KB on return
-template <int VW, int KB>
-__device__ __forceinline__ void solve_block_step_bf16(f32x4 (&T)[Geo<VW>::NT], float (&b)[VW], float (&zcol)[VW],
-                                                      float (&pend)[VW], TilePieces (&U)[VW], TilePieces (&nU)[VW],
-                                                      bool &ok, const int lane) {
-    const f32x4 X = diag_inverse_factor(T[tile_index(KB, KB, VW)], lane, ok, PendingFiller<VW, KB>{T, U, nU});
-    T[tile_index(KB, KB, VW)] = X;      // the diagonal tile is dead once factored: its slot keeps X for the back substitution
-    if constexpr (KB + 1 < VW) {
-        const TilePieces Xp = split_tile(X);
-#pragma unroll
-        for (int jb = KB + 1; jb < VW; ++jb) {      // panel solves U_kj = X^T A_kj
-            const TilePieces Zp = split_tile(T[tile_index(KB, jb, VW)]);
-            f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f};
-            tile_xtz_pieces(Xp, Zp, u);
-            T[tile_index(KB, jb, VW)] = u;
-            U[jb] = split_tile(u);
-            nU[jb] = negated(U[jb]);
-        }
-        // the next diagonal tile's update at once: its elimination starts the next step
-        tile_xtz_pieces(nU[KB + 1], U[KB + 1], T[tile_index(KB + 1, KB + 1, VW)]);
-    }
-    if constexpr (KB > 0) b[KB] -= grp_sum4(pend[KB]);
-    zcol[KB] = tile_xt_v(X, vec_col_to_row(b[KB], lane));          // z_kb = U_kk^{-T} b_kb
-    const f32x4 zrow = vec_col_to_row(zcol[KB], lane);
-#pragma unroll
-    for (int ib = KB + 1; ib < VW; ++ib) {
-        const f32x4 Ui = T[tile_index(KB, ib, VW)];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) pend[ib] = fmaf(Ui[r], zrow[r], pend[ib]);
-    }
-    __builtin_amdgcn_sched_barrier(0);   // block steps stay in order: bounds the live ranges
-}
-template <int VW, int... KBs>
-__device__ __forceinline__ void solve_block_steps_bf16(f32x4 (&T)[Geo<VW>::NT], float (&b)[VW], float (&zcol)[VW],
-                                                       float (&pend)[VW], TilePieces (&U)[VW], TilePieces (&nU)[VW],
-                                                       bool &ok, const int lane, std::integer_sequence<int, KBs...>) {
-    (solve_block_step_bf16<VW, KBs>(T, b, zcol, pend, U, nU, ok, lane), ...);
-}
-template <int VW>
-__device__ __forceinline__ bool blocked_solve_bf16(f32x4 (&T)[Geo<VW>::NT], float (&b)[VW], float (&x)[VW], const int lane) {
-    float zcol[VW], pend[VW];
-#pragma unroll
-    for (int t = 0; t < VW; ++t) pend[t] = 0.f;
-    TilePieces U[VW], nU[VW];
-    bool ok = true;
-    solve_block_steps_bf16<VW>(T, b, zcol, pend, U, nU, ok, lane, std::make_integer_sequence<int, VW>{});
-    back_substitute<VW>(T, zcol, x, lane);
-    return ok;
 }
 
 // ----------------------------------------------------------------------------- CG on the formed matrix
@@ -1233,9 +834,13 @@ struct SweepOpts {
     bool split;                 // bf16 x 3 accumulate (where the kernel has it)
     int row_kernel;             // ALS_ROW_KERNEL_*
     hipEvent_t tap0, tap1;
+    const float *whitened;      // table of als_whiten_f32 for the fixed factor, or null: no short-row form
+    int64_t ldw;
+    const int64_t *bounds;      // host: als_plan_short_bounds
 };
 inline int32_t read_opts(const als_sweep_opts_t *o, SweepOpts &out) {
     out.split = true; out.row_kernel = ALS_ROW_KERNEL_AUTO; out.tap0 = out.tap1 = nullptr;
+    out.whitened = nullptr; out.ldw = 0; out.bounds = nullptr;
     if (!o) return ALS_OK;
     if (o->accumulate != ALS_ACCUMULATE_DEFAULT && o->accumulate != ALS_ACCUMULATE_FP32 &&
         o->accumulate != ALS_ACCUMULATE_BF16X3)
@@ -1248,6 +853,12 @@ inline int32_t read_opts(const als_sweep_opts_t *o, SweepOpts &out) {
     out.row_kernel = o->row_kernel;
     out.tap0 = (hipEvent_t)o->tap_begin;
     out.tap1 = (hipEvent_t)o->tap_end;
+    if (o->whitened) {
+        if (!o->short_bounds) return fail(ALS_ERR_INVALID_ARG, "als_sweep_opts_t: whitened without short_bounds");
+        if (o->ld_whitened % 4 || (uintptr_t)o->whitened % 16)
+            return fail(ALS_ERR_INVALID_ARG, "als_sweep_opts_t: the whitened table needs 16-byte aligned rows");
+        out.whitened = o->whitened; out.ldw = o->ld_whitened; out.bounds = o->short_bounds;
+    }
     return ALS_OK;
 }
 
@@ -1255,6 +866,24 @@ template <int VW>
 static int32_t half_sweep_impl(const SweepParams &p, int64_t n_rows, int64_t n_items, int64_t n_long,
                                double *absdiff_out, double *diff_partials, bool vec, const SweepOpts &o, hipStream_t st) {
     if (o.tap0) ALS_HIP_CHECK(hipEventRecord(o.tap0, st));
+    // Short rows (at most 16 nb_max entries) in their entry-space form (als_short_rows.hip) when the caller handed in
+    // the whitened table of the fixed factor: the plan's whole rows are sorted by entry count, so they are the tail
+    // [bounds[nb_max], n_items) of the item list, and the kernels below stop in front of it.  Exact solve only.
+    const int64_t n_items_all = n_items;
+    int nb_max = 0;
+    if (o.whitened && p.cg_steps == 0) {
+        nb_max = als_short_rows_max_groups(p.f);
+        if (nb_max == 0) return fail(ALS_ERR_UNSUPPORTED, "the short-row form exists for 32 < f <= 128, f a multiple of 4 (f=%d)", p.f);
+        const int64_t *b = o.bounds;
+        const int64_t n_chunk_items = n_items - (n_rows - n_long);
+        for (int j = 0; j <= ALS_SHORT_MAX_GROUPS; ++j)
+            if (b[j] < n_chunk_items || b[j] > n_items || (j > 0 && b[j] > b[j - 1]))
+                return fail(ALS_ERR_INVALID_ARG, "short_bounds do not belong to this plan");
+        if (b[ALS_SHORT_MAX_GROUPS + 1] != n_items) return fail(ALS_ERR_INVALID_ARG, "short_bounds do not belong to this plan");
+        if (o.ldw < 2 * (int64_t)p.f) return fail(ALS_ERR_INVALID_ARG, "ld_whitened < 2 f");
+        n_items = b[nb_max];
+    }
+    const int64_t n_short = n_items_all - n_items;
     // 64 < f <= 128 with 16-byte aligned rows and the bf16 x 3 accumulate: the whole rows can go to the persistent
     // stream kernel (als_row_stream.inc)
     int rk = ALS_ROW_KERNEL_WAVE;
@@ -1270,7 +899,7 @@ static int32_t half_sweep_impl(const SweepParams &p, int64_t n_rows, int64_t n_i
             int dev = 0, cus = 0;
             ALS_HIP_CHECK(hipGetDevice(&dev));
             ALS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-            if (n_rows - n_long >= 4 * (int64_t)std::max(cus, 1)) rk = ALS_ROW_KERNEL_STREAM;
+            if (n_rows - n_long - n_short >= 4 * (int64_t)std::max(cus, 1)) rk = ALS_ROW_KERNEL_STREAM;
         }
     } else if (o.row_kernel == ALS_ROW_KERNEL_STREAM) {
         return fail(ALS_ERR_UNSUPPORTED, "row_kernel STREAM exists for 64 < f <= 128 only (f=%d)", p.f);
@@ -1278,7 +907,7 @@ static int32_t half_sweep_impl(const SweepParams &p, int64_t n_rows, int64_t n_i
     if (n_items > 0 && rk == ALS_ROW_KERNEL_STREAM) {
         if constexpr (VW == 8) {
             // the plan lists the chunk items of long rows first (one per partial slot), then the whole rows
-            const int64_t n_chunk_items = n_items - (n_rows - n_long), n_whole = n_rows - n_long;
+            const int64_t n_whole = n_rows - n_long - n_short, n_chunk_items = n_items - n_whole;
             int dev = 0, cus = 0;
             ALS_HIP_CHECK(hipGetDevice(&dev));
             ALS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -1328,6 +957,11 @@ static int32_t half_sweep_impl(const SweepParams &p, int64_t n_rows, int64_t n_i
         hipLaunchKernelGGL(sweep_long_rows_kernel<VW>, dim3((unsigned)n_long), dim3(64), 0, st, p);
         ALS_HIP_CHECK(hipGetLastError());
     }
+    if (n_short > 0) {
+        const int32_t rc = als_short_rows_launch_(p.col, p.val, p.row_ids, p.items, o.bounds, nb_max, o.whitened, o.ldw, p.f,
+                                                  p.alpha, p.X, p.ldx, p.rowdiff, p.info, st);
+        if (rc) return rc;
+    }
     if (o.tap1) ALS_HIP_CHECK(hipEventRecord(o.tap1, st));      // every per-row kernel of the half-sweep lies between the taps
     if (absdiff_out) return als_sum_rowdiff_(p.rowdiff, n_rows, diff_partials, absdiff_out, st);
     return ALS_OK;
@@ -1360,7 +994,7 @@ extern "C" {
 
 const char *als_last_error_string(void) { return g_err; }
 
-int32_t als_abi_version(void) { return 5; }
+int32_t als_abi_version(void) { return 6; }
 
 // ----------------------------------------------------------------------------- plan
 int32_t als_plan_count(const int64_t *rowptr, int64_t n_rows, int32_t chunk_nnz, int64_t *n_items, int64_t *n_long,

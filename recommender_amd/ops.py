@@ -72,7 +72,7 @@ def sweep_opts(accumulate="default", row_kernel="auto", tap=None):
         raise ValueError("row_kernel must be one of %s" % sorted(_lib.ROW_KERNELS))
     if accumulate == "default" and row_kernel == "auto" and tap is None:
         return None
-    o = _lib.SweepOpts(_lib.ACCUMULATE_MODES[accumulate], _lib.ROW_KERNELS[row_kernel], None, None)
+    o = _lib.SweepOpts(_lib.ACCUMULATE_MODES[accumulate], _lib.ROW_KERNELS[row_kernel], None, None, None, 0, None)
     if tap is not None:
         o.tap_begin, o.tap_end = tap[0].cuda_event, tap[1].cuda_event
         o._tap = tap            # keeps the events alive, and lets a call made of several library calls record them itself
@@ -139,6 +139,11 @@ class DeviceCSR:
         self.device = dev
         items, long_rows, self.n_slots = build_plan(host_ptr, chunk_nnz)
         self.n_items, self.n_long = items.shape[0], long_rows.shape[0]
+        # whole rows are listed by entry count: short_bounds[j] = first item with at most 16 j entries (host array,
+        # handed to the half-sweep when it solves short rows in their entry-space form)
+        self.short_bounds = np.zeros(_lib.SHORT_MAX_GROUPS + 2, dtype=np.int64)
+        check(lib.als_plan_short_bounds(host_ptr.ctypes.data, n_rows, self.chunk_nnz, self.short_bounds.ctypes.data),
+              "als_plan_short_bounds")
         self.rowptr = rowptr
         if self.nnz == 0:   # keep the pointers non-null for a matrix without entries
             col = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -245,6 +250,8 @@ class GramCache:
         self.gram = torch.zeros((f, f), dtype=torch.float32, device=device)
         self.tiles = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
         self._ws = None
+        self.whitened = None        # [n, 2 f] table of whiten() for the factor this Gram belongs to, or None
+        self._wws = None
 
 
 def gram(Y, lamb, out=None, n=None):
@@ -265,6 +272,35 @@ def gram(Y, lamb, out=None, n=None):
         check(lib.als_gram_f32(_ptr(Y), n, f, ldy, float(lamb), _ptr(out.gram), _ptr(out.tiles), _ptr(out._ws),
                                out._ws.numel(), _stream()), "als_gram_f32")
     return out
+
+
+def short_rows_max_entries(f):
+    """Rows with at most this many stored entries can be solved in their entry-space form (0: not for this f)."""
+    return 16 * int(lib.als_short_rows_max_groups(int(f)))
+
+
+def whiten(Y, cache, n=None, info=None):
+    """The table the short-row form of the half-sweep gathers from: cache.whitened[i] = [ y_i R^-1 | y_i G^-1 ] with
+    G = cache.gram + lamb I = R^T R (als_whiten_f32).  cache must hold the Gram of these rows of Y (ops.gram just
+    before).  The table is kept in the cache and reused as a buffer by the next call."""
+    ldy = _factor_ld(Y, "Y")
+    n = Y.shape[0] if n is None else int(n)
+    f = Y.shape[1]
+    if cache.f != f or not (1 <= n <= Y.shape[0]):
+        raise ValueError("cache and Y disagree (f=%d, cache f=%d, n=%d)" % (f, cache.f, n))
+    need = lib.als_whiten_workspace_bytes(f)
+    if need == 0:
+        raise ValueError("the short-row form exists for 32 < f <= 128 with f a multiple of 4 (f=%d)" % f)
+    if cache._wws is None:
+        cache._wws = torch.empty(need, dtype=torch.uint8, device=Y.device)
+    wz = cache.whitened
+    if wz is None or wz.shape[0] < n or wz.device != Y.device:
+        wz = cache.whitened = torch.empty((n, 2 * f), dtype=torch.float32, device=Y.device)
+    _same_device(Y, cache.gram, wz, cache._wws, info)
+    with torch.cuda.device(Y.device):
+        check(lib.als_whiten_f32(_ptr(cache.gram), float(cache.lamb), f, _ptr(Y), n, ldy, _ptr(wz), wz.stride(0), _ptr(info),
+                                 _ptr(cache._wws), cache._wws.numel(), _stream()), "als_whiten_f32")
+    return wz
 
 
 def gram_partials(Y, row_begin, row_end, super_out=None, ws=None):
@@ -305,12 +341,15 @@ def gram_finalize(super_partials, f, lamb, out=None):
 
 
 # ----------------------------------------------------------------------------- half sweep
-def half_sweep(csr, Yopp, gram_cache, Xown, alpha, absdiff=None, info=None, opts=None, static_scratch=False):
+def half_sweep(csr, Yopp, gram_cache, Xown, alpha, absdiff=None, info=None, opts=None, static_scratch=False,
+               short_rows=False):
     """One half-sweep: every row of `csr` re-solves its row of Xown (in place) against the
     fixed factor Yopp.  Returns the device scalar sum|X_old - X_new| (float64, 1 element);
     divide by n*k for run_als_epoch's return value (reclibwh/core/ALS.py:233).  opts: sweep_opts(...).
     static_scratch=True: als_half_sweep_csr_static_f32 - no workspace is allocated or passed, the library's built-in
-    per-GPU scratch buffer is used (small inputs only; absdiff must then be given to keep the call allocation free)."""
+    per-GPU scratch buffer is used (small inputs only; absdiff must then be given to keep the call allocation free).
+    short_rows=True: rows with at most short_rows_max_entries(f) stored entries are solved in their entry-space form
+    from gram_cache.whitened (ops.whiten(Yopp, gram_cache) after ops.gram; the same solution to float32 rounding)."""
     if not isinstance(csr, DeviceCSR):
         raise ValueError("csr must be a DeviceCSR")
     ldy = _factor_ld(Yopp, "Yopp")
@@ -329,6 +368,16 @@ def half_sweep(csr, Yopp, gram_cache, Xown, alpha, absdiff=None, info=None, opts
         raise ValueError("Xown and Yopp must not alias")
     if absdiff is None:
         absdiff = torch.zeros(1, dtype=torch.float64, device=csr.device)
+    if short_rows:
+        wz = gram_cache.whitened
+        if wz is None or wz.shape[0] < csr.shape[1] or wz.shape[1] != 2 * f or wz.device != csr.device:
+            raise ValueError("short_rows=True needs gram_cache.whitened for this factor (ops.whiten)")
+        o = _lib.SweepOpts(0, 0, None, None, None, 0, None)
+        if opts is not None:
+            o.accumulate, o.row_kernel, o.tap_begin, o.tap_end = opts.accumulate, opts.row_kernel, opts.tap_begin, opts.tap_end
+        o.whitened, o.ld_whitened, o.short_bounds = wz.data_ptr(), wz.stride(0), csr.short_bounds.ctypes.data
+        o._keep = (opts, wz, csr.short_bounds)
+        opts = o
     if static_scratch:
         with torch.cuda.device(csr.device):
             check(lib.als_half_sweep_csr_static_f32(
@@ -390,7 +439,7 @@ def half_sweep_cg(csr, Yopp, gram_cache, Xown, alpha, cg_steps, absdiff=None, in
         parts = torch.zeros(len(slabs), dtype=torch.float64, device=csr.device)
         tap = getattr(opts, "_tap", None) if opts is not None else None
         if tap is not None:         # the tap brackets all slabs, not the last one
-            opts = _lib.SweepOpts(opts.accumulate, opts.row_kernel, None, None)
+            opts = _lib.SweepOpts(opts.accumulate, opts.row_kernel, None, None, None, 0, None)
             with torch.cuda.device(csr.device):
                 tap[0].record(torch.cuda.current_stream())
         for k, (r0, r1, sub) in enumerate(slabs):

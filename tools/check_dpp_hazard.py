@@ -19,7 +19,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "recommender_amd", "csrc")
-SOURCES = ["als_kernels.hip", "als_cg.hip", "als_scoring.hip"]
+SOURCES = ["als_kernels.hip", "als_cg.hip", "als_scoring.hip", "als_short_rows.hip"]
 
 
 def makefile_flags():
