@@ -111,25 +111,24 @@ def _host_staged(T, group):
     return T.is_cuda and torch.distributed.get_backend(group) != "nccl"
 
 
-_PADDED_RECV = {}      # (device, dtype, world, cap, trailing shape) -> (receive, send) buffers of the padded form, allocated once
-# Blocks of different sizes over RCCL: "padded" (default) = one all_gather_into_tensor through the persistent padded
-# buffer, the collective every RCCL build runs; "list" = all_gather into T's own row-block views (torch turns it into one
-# broadcast per rank inside one RCCL group: no staging pass, but a path that has not run on more than one GPU here).
-import os as _os
-_UNEVEN_LIST_OK = [_os.environ.get("ALS_ALLGATHERV", "padded") == "list"]
+_PADDED_RECV = {}      # (device, dtype, world, trailing shape) -> (receive, send) buffers of the padded form, grown on demand
+UNEVEN_FORMS = ("padded", "list")
 
 
-def _all_gather_row_blocks(T, starts, sizes, rank, group):
+def _all_gather_row_blocks(T, starts, sizes, rank, group, uneven="padded"):
     """All-gather of one row block per rank of the replicated T, in place: rank r owns
     T[starts[r] : starts[r] + sizes[r]] and every rank ends up with all of them:
 
       * RCCL, equal blocks that tile T: all_gather_into_tensor straight into T;
       * RCCL, equal blocks elsewhere: all_gather into the list of T's own row-block views;
-      * RCCL, blocks of different sizes: padded to the longest through ONE receive buffer that is allocated once and
-        kept (one all_gather_into_tensor, then each block is copied to its place); with ALS_ALLGATHERV=list instead
-        all_gather into the views, which torch issues as one broadcast per rank inside one RCCL group (every receive
-        lands in place) - should the backend refuse that form, the padded one takes over;
+      * RCCL, blocks of different sizes, uneven="padded": padded to the longest through ONE receive buffer per
+        (device, dtype, world, row shape) that is kept and only ever grows (one all_gather_into_tensor, then each
+        block is copied to its place: a second copy of the gathered rows and one more pass over them);
+        uneven="list": all_gather into the views, which torch issues as one broadcast per rank inside one RCCL
+        group - every receive lands in place, no staging buffer, no copy pass;
       * other backends (gloo in tests): one broadcast per rank of host copies - they get host tensors (_host_staged)."""
+    if uneven not in UNEVEN_FORMS:
+        raise ValueError("uneven must be one of %s" % (UNEVEN_FORMS,))
     world = len(sizes)
     if max(sizes) == 0:
         return
@@ -152,42 +151,38 @@ def _all_gather_row_blocks(T, starts, sizes, rank, group):
     if equal and T.is_contiguous() and all(starts[r] == r * sizes[0] for r in range(world)) and sizes[0] * world == T.shape[0]:
         torch.distributed.all_gather_into_tensor(T, mine, group=group)      # blocks tile T: no staging at all
         return
-    views = [T[starts[r]: starts[r] + sizes[r]] for r in range(world)]
-    if equal or _UNEVEN_LIST_OK[0]:
-        try:
-            torch.distributed.all_gather(views, mine, group=group)
-            return
-        except (RuntimeError, ValueError):
-            if equal:
-                raise
-            _UNEVEN_LIST_OK[0] = False      # the same on every rank: the sizes are checked before anything is sent
+    if equal or uneven == "list":
+        torch.distributed.all_gather([T[starts[r]: starts[r] + sizes[r]] for r in range(world)], mine, group=group)
+        return
     _all_gather_padded(T, starts, sizes, rank, group)
 
 
 def _all_gather_padded(T, starts, sizes, rank, group):
     """Row blocks of different sizes, padded to the longest: ONE all_gather_into_tensor through a receive and a send
-    buffer that are allocated once per (device, dtype, world, longest block, row shape) and kept; then every other
-    rank's block is copied to its place in T."""
+    buffer kept per (device, dtype, world, row shape) - sized for the longest block seen so far, so the chunks of an
+    overlapped sweep share one pair -, then every other rank's block is copied to its place in T."""
     world = len(sizes)
     cap = max(sizes)
-    key = (T.device, T.dtype, world, cap, tuple(T.shape[1:]))
+    tail = tuple(T.shape[1:])
+    key = (T.device, T.dtype, world, tail)
     bufs = _PADDED_RECV.get(key)
-    if bufs is None:        # a send buffer of its own: no reliance on in-place collectives
-        bufs = _PADDED_RECV[key] = (torch.empty((world, cap) + tuple(T.shape[1:]), dtype=T.dtype, device=T.device),
-                                    torch.zeros((cap,) + tuple(T.shape[1:]), dtype=T.dtype, device=T.device))
-    recv, send = bufs
+    if bufs is None or bufs[1].shape[0] < cap:        # a send buffer of its own: no reliance on in-place collectives
+        bufs = _PADDED_RECV[key] = (torch.empty((world * cap,) + tail, dtype=T.dtype, device=T.device),
+                                    torch.zeros((cap,) + tail, dtype=T.dtype, device=T.device))
+    recv = bufs[0][: world * cap].view((world, cap) + tail)
+    send = bufs[1][:cap]
     send[: sizes[rank]] = T[starts[rank]: starts[rank] + sizes[rank]]
-    torch.distributed.all_gather_into_tensor(recv.view((world * cap,) + tuple(T.shape[1:])), send, group=group)
+    torch.distributed.all_gather_into_tensor(recv.view((world * cap,) + tail), send, group=group)
     for r in range(world):
         if r != rank and sizes[r]:
             T[starts[r]: starts[r] + sizes[r]].copy_(recv[r, : sizes[r]])
 
 
-def _all_gather_rows(T, bounds, rank, group):
+def _all_gather_rows(T, bounds, rank, group, uneven="padded"):
     """In-place all-gather of the row shards [bounds[r], bounds[r+1]) of the replicated T."""
     world = len(bounds) - 1
     _all_gather_row_blocks(T, [int(bounds[r]) for r in range(world)],
-                           [int(bounds[r + 1] - bounds[r]) for r in range(world)], rank, group)
+                           [int(bounds[r + 1] - bounds[r]) for r in range(world)], rank, group, uneven)
 
 
 def _chunk_cuts(n, parts):
@@ -213,8 +208,14 @@ class ALSEngine:
     """
 
     def __init__(self, csr_users, csr_items, X, Y, lamb, alpha, user_bounds=None, item_bounds=None, group=None,
-                 backend=ops, overlap_chunks=None, solver="auto", cg_steps=10, cg_form="auto", short_rows="auto"):
+                 backend=ops, overlap_chunks=None, solver="auto", cg_steps=10, cg_form="auto", short_rows="auto",
+                 uneven_exchange="padded"):
         self.group = group
+        if uneven_exchange not in UNEVEN_FORMS:
+            raise ValueError("uneven_exchange must be one of %s" % (UNEVEN_FORMS,))
+        # how RCCL exchanges shards of different sizes: "padded" (one all_gather_into_tensor through a kept
+        # buffer + a copy pass) or "list" (receives land in place; see _all_gather_row_blocks)
+        self.uneven_exchange = uneven_exchange
         self.backend = backend      # the HIP operators; tests inject a CPU stand-in to exercise the sharding logic
         self.world = torch.distributed.get_world_size(group) if group is not None else 1
         self.rank = torch.distributed.get_rank(group) if group is not None else 0
@@ -326,16 +327,16 @@ class ALSEngine:
             if on_gpu:
                 self._side.wait_stream(torch.cuda.current_stream(self.X.device))
                 with torch.cuda.stream(self._side):
-                    _all_gather_row_blocks(self.X, starts, sizes, self.rank, self.group)
+                    _all_gather_row_blocks(self.X, starts, sizes, self.rank, self.group, self.uneven_exchange)
                     done.append(self._side.record_event())
             else:
-                _all_gather_row_blocks(self.X, starts, sizes, self.rank, self.group)
+                _all_gather_row_blocks(self.X, starts, sizes, self.rank, self.group, self.uneven_exchange)
         for ev in done:
             torch.cuda.current_stream(self.X.device).wait_event(ev)
         if len(parts) > 1:
             torch.sum(torch.cat([p[3] for p in parts]), 0, keepdim=True, out=self._dX)
         if self.world > 1 and not chunked:
-            _all_gather_rows(self.X[: self.n_users], self.user_bounds, self.rank, self.group)
+            _all_gather_rows(self.X[: self.n_users], self.user_bounds, self.rank, self.group, self.uneven_exchange)
 
     # one ALS iteration = X half-sweep + Y half-sweep, Gram refreshes included
     def step(self):
@@ -352,7 +353,7 @@ class ALSEngine:
                           self.backend, self.cg_steps, self.cg_form, self.sweep_opts("items") if self.sweep_opts else None,
                           self.short["items"])
         if self.world > 1:
-            _all_gather_rows(self.Y[: self.n_items], self.item_bounds, self.rank, self.group)
+            _all_gather_rows(self.Y[: self.n_items], self.item_bounds, self.rank, self.group, self.uneven_exchange)
 
     def last_delta(self):
         """mean|dX| + mean|dY| of the last step, as ALSRef.train's trace (ALS.py:136-139).

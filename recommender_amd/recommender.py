@@ -34,6 +34,8 @@ DEFAULTS = dict(f=20,           # ALS.json.template:26 (the reference's layer wi
                 cg_steps=10,        # conjugate-gradient steps per row and half-sweep when solver is "cg": the count
                                     # at which 15 iterations give the exact solve's MAP@200 / precision@10 / RMSE
                                     # to 3 decimals on the ml-latest-small-shaped configuration (3 and 6 do not)
+                short_rows="auto",  # exact solver: rows with fewer ratings than factors solved in their entry-space form
+                                    # ("auto": where it pays, als.short_rows_pay; True / False)
                 med_score=3.0,      # ALS.py:402
                 eval_lim=200)       # EvalProto.py:22
 
@@ -119,7 +121,7 @@ class RecommenderALS:
         cu = ops.DeviceCSR.from_scipy(self.Utrain, self.device, c["chunk_nnz"])
         ci = cu.transpose()             # on the device (the reference transposes on the host, ALS.py:432)
         self.engine = ALSEngine(cu, ci, self.X, self.Y, c["lamb"], c["alpha"], solver=c["solver"],
-                                cg_steps=c["cg_steps"])
+                                cg_steps=c["cg_steps"], short_rows=c["short_rows"])
 
     # ------------------------------------------------------------------ training
     def train(self, epochs=None, evaluate=None):
@@ -191,6 +193,19 @@ class RecommenderALS:
             for k in ("epochs", "alpha", "lamb"):
                 if k in cfg: self.config[k] = cfg[k]
             self.start_epoch = int(cfg.get("start_epoch", 0))
+        # the epochs already run: a resumed train() appends to them, as the reference's callback keeps its
+        # per-epoch scores across epochs and writes them all (EvalProto.py:74-94)
+        self.eval_epochs, self.eval_scores, self.trace = [], [], []
+        evp, trp = os.path.join(path, "eval.csv"), os.path.join(path, "trace.csv")
+        if os.path.exists(evp):
+            with open(evp) as fp:
+                for line in fp.read().strip().split("\n")[1:]:
+                    e, sc = line.split(",")
+                    if float(e) < self.start_epoch:
+                        self.eval_epochs.append(int(float(e))); self.eval_scores.append(float(sc))
+        if os.path.exists(trp):
+            with open(trp) as fp:
+                self.trace = [float(t) for t in fp.read().strip().split("\n")[1:]][: self.start_epoch]
         self.engine = None
         self._foldin_cache = None
         return self

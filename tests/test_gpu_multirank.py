@@ -101,6 +101,14 @@ def _rccl_single_rank(rank, port):
         als._all_gather_row_blocks(T, [2], [5], 0, g)
         ev = side.record_event()
     torch.cuda.current_stream().wait_event(ev)
+    # both forms for shards of different sizes, as far as one rank can walk them: the list form (receives land in the
+    # tensor's own views) and the padded form (kept buffer + copy-out), the latter twice so that the buffer is reused
+    als._all_gather_row_blocks(T, [1], [6], 0, g, uneven="list")
+    als._all_gather_padded(T, [2], [5], 0, g)
+    als._all_gather_padded(T, [0], [3], 0, g)
+    assert len(als._PADDED_RECV) == 1 and next(iter(als._PADDED_RECV.values()))[1].shape[0] == 5
+    with pytest.raises(ValueError):
+        als._all_gather_row_blocks(T, [0], [10], 0, g, uneven="ring")
     d = torch.ones(2, dtype=torch.float64, device=dev)
     torch.distributed.all_reduce(d, group=g)
     torch.distributed.barrier()

@@ -74,11 +74,41 @@ def test_save_load_predict_roundtrip(ra, golden, tmp_path):
     # (epochs included) replaces the constructor's, as ALSTrainer.__env_restore does (ALS.py:297-298)
     cont = ra.RecommenderALS(mode="train", als_kwargs={"f": 20, "lamb": 0.5, "alpha": 1.0, "epochs": 9})
     cont.load(path); cont.input_data(U)
-    assert cont.config["epochs"] == 2 and cont.config["lamb"] == 0.01 and cont.train() == []
+    assert cont.config["epochs"] == 2 and cont.config["lamb"] == 0.01
+    assert cont.train() == [float(t) for t in rec.trace] and cont.start_epoch == 2       # nothing left to run
+    assert cont.trace == [float(t) for t in rec.trace]             # the saved epochs' trace is read back ...
     cont.train(epochs=3)
-    assert cont.start_epoch == 3 and len(cont.trace) == 1
+    assert cont.start_epoch == 3 and len(cont.trace) == 3         # ... and the resumed epoch appended to it
     ref = np.abs(cont.X.cpu().numpy() - g["K20_ref_X3"]).max() / np.abs(g["K20_ref_X3"]).max()
     assert ref < 1e-4
+
+
+def test_resumed_run_appends_to_eval_csv(ra, golden, tmp_path):
+    """The reference's callback keeps every epoch's score and writes them all (EvalProto.py:74-94): a run that is
+    saved, loaded and continued must end with one eval.csv line per epoch, not only the resumed ones."""
+    g, U = _g2(golden)
+    rng = np.random.default_rng(0)
+    coo = U.tocoo()
+    test = rng.random(coo.nnz) < 0.2
+    tr = sps.csr_matrix((coo.data[~test], (coo.row[~test], coo.col[~test])), shape=U.shape)
+    te = sps.csr_matrix((coo.data[test], (coo.row[test], coo.col[test])), shape=U.shape)
+    path = str(tmp_path / "model")
+    kw = {"f": 20, "lamb": 0.01, "alpha": 40.0, "epochs": 2}
+    rec = ra.RecommenderALS(mode="train", n_users=U.shape[0], n_items=U.shape[1], als_kwargs=kw, model_path=path)
+    rec.input_data((tr, te)); rec.train()
+    first = open(os.path.join(path, "eval.csv")).read().strip().split("\n")
+    assert first[0] == "epoch,score" and len(first) == 3
+    cont = ra.RecommenderALS(mode="train", als_kwargs=kw, model_path=path)
+    cont.load(path); cont.input_data((tr, te))
+    assert cont.eval_epochs == [0, 1] and cont.eval_scores == [float(x) for x in rec.eval_scores]
+    cont.train(epochs=4)
+    lines = open(os.path.join(path, "eval.csv")).read().strip().split("\n")
+    assert lines[:3] == first and [float(l.split(",")[0]) for l in lines[1:]] == [0.0, 1.0, 2.0, 3.0]
+    assert len(open(os.path.join(path, "trace.csv")).read().strip().split("\n")) == 5
+    # one uninterrupted run of 4 epochs ends with the same scores
+    one = ra.RecommenderALS(mode="train", n_users=U.shape[0], n_items=U.shape[1], als_kwargs=dict(kw, epochs=4))
+    one.input_data((tr, te)); one.train()
+    np.testing.assert_allclose(cont.eval_scores, one.eval_scores, rtol=0, atol=1e-6)
 
 
 def test_recommend_and_similar_match_reference_ranking(ra):
