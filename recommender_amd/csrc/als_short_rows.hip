@@ -227,65 +227,127 @@ __global__ __launch_bounds__(64, short_waves(NB)) void short_rows_kernel(const S
 }
 
 // ----------------------------------------------------------------------------- whitening table
-// One workgroup: G = gram + lamb I in float64, its Cholesky factor R (upper), R^-1 and G^-1 = R^-1 R^-T, all in LDS;
-// writes the float32 table B [2 f, f] that the whitening GEMM takes as its "item" rows:
-//     B[j]     = column j of R^-1   (so <y, B[j]>     = (y R^-1)[j]),
-//     B[f + j] = row j of G^-1      (so <y, B[f + j]> = (y G^-1)[j]).
+// One workgroup of 1024 threads: G = gram + lamb I in float64, its Cholesky factor G = L L^T, X = L^-1 and
+// G^-1 = X^T X; writes the float32 table B [2 f, f] that the whitening GEMM takes as its "item" rows:
+//     B[j]     = row j of L^-1 = column j of R^-1 (R = L^T)   (so <y, B[j]>     = (y R^-1)[j]),
+//     B[f + j] = row j of G^-1                                  (so <y, B[f + j]> = (y G^-1)[j]).
+// Thread (ty, tx) of 32 x 32 keeps elements (ty + 32 a, tx + 32 b), a, b < 4, of the Schur complement and of X in registers.
+// Step k of the right-looking factorisation needs column k of the complement and row k of X: their owners put them
+// into LDS (two buffers, by the parity of k: one barrier per step) and every thread updates its 2 x 16 elements:
+//     S[r][c] -= s_rk s_ck / s_kk,   X[k][:] = x_k / sqrt(s_kk),   X[r][:] -= s_rk x_k / s_kk   (r > k)
+// - the forward substitution L X = I carried along with the factorisation.
 // info (optional) is incremented when G is not positive definite in float64 (the table is then NaN).
 constexpr int WH_MAX_F = 128;
 constexpr int WH_LD = WH_MAX_F + 1;      // odd row pitch: column walks hit different LDS banks
-__global__ __launch_bounds__(1024) void whiten_factor_kernel(const float *__restrict__ gram, const float lamb, const int f,
-                                                             float *__restrict__ B, int32_t *info) {
-    __shared__ double A[WH_MAX_F * WH_LD];      // upper triangle: G, then R; strictly lower triangle: (R^-1)^T
-    __shared__ double dd[WH_MAX_F];             // 1 / R_kk
-    __shared__ int bad;
-    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
-    if (tid == 0) bad = 0;
-    for (int e = tid; e < f * f; e += 1024) {
-        const int r = e / f, c = e % f;
-        A[r * WH_LD + c] = (double)gram[e] + (r == c ? (double)lamb : 0.0);
-    }
-    __syncthreads();
-    // right-looking Cholesky without scaling: after step k, rows > k hold the Schur complement; row k keeps
-    // a_kj (j >= k) of its own complement, so R_kj = a_kj / sqrt(a_kk)
+constexpr int WH_T = 32;                 // threads per side (1024 threads; 16 x 16 threads with 8 x 8 elements each measured slower)
+constexpr int WH_E = WH_MAX_F / WH_T;    // elements per thread and side
+__global__ __launch_bounds__(WH_T * WH_T) void whiten_factor_kernel(const float *__restrict__ gram, const float lamb,
+                                                                    const int f, float *__restrict__ B, int32_t *info) {
+    __shared__ double Xs[WH_MAX_F * WH_LD];
+    __shared__ double colk[2][WH_MAX_F], rowx[2][WH_MAX_F];
+    const int tid = threadIdx.x, tx = tid % WH_T, ty = tid / WH_T;
+    double S[WH_E][WH_E], X[WH_E][WH_E];
+#pragma unroll
+    for (int a = 0; a < WH_E; ++a)
+#pragma unroll
+        for (int b = 0; b < WH_E; ++b) {
+            const int r = ty + WH_T * a, c = tx + WH_T * b;
+            const bool in = r < f && c < f;
+            S[a][b] = in ? (double)gram[r * f + c] + (r == c ? (double)lamb : 0.0) : (r == c ? 1.0 : 0.0);
+            X[a][b] = r == c ? 1.0 : 0.0;
+        }
+    bool bad = false;
     for (int k = 0; k < f; ++k) {
-        const double dkk = A[k * WH_LD + k];
-        if (tid == 0 && !(dkk > 0.0)) bad = 1;
-        const double rk = 1.0 / dkk;
-        for (int r = k + 1 + ty; r < f; r += 32) {
-            const double m = A[k * WH_LD + r] * rk;
-            for (int c = r + tx; c < f; c += 32) A[r * WH_LD + c] -= m * A[k * WH_LD + c];
+        const int kq = k / WH_T, kr = k % WH_T, par = k & 1;
+        // column k of the complement and row k of X, from their owners (kq is uniform: the branch picks the register)
+#pragma unroll
+        for (int q = 0; q < WH_E; ++q) {
+            if (kq != q) continue;
+            if (tx == kr) {
+#pragma unroll
+                for (int a = 0; a < WH_E; ++a) colk[par][ty + WH_T * a] = S[a][q];
+            }
+            if (ty == kr) {
+#pragma unroll
+                for (int b = 0; b < WH_E; ++b) rowx[par][tx + WH_T * b] = X[q][b];
+            }
         }
         __syncthreads();
-    }
-    if (tid < f) dd[tid] = 1.0 / sqrt(A[tid * WH_LD + tid]);
-    __syncthreads();
-    for (int e = tid; e < f * f; e += 1024) {
-        const int r = e / f, c = e % f;
-        if (c >= r) A[r * WH_LD + c] *= dd[r];      // R (its diagonal is 1 / dd)
-    }
-    __syncthreads();
-    // R^-1, column j by thread j (back substitution): (R^-1)_ij, i < j, goes to A[j][i]; (R^-1)_jj = dd[j]
-    if (tid < f) {
-        const int j = tid;
-        for (int r = j - 1; r >= 0; --r) {
-            double s = A[r * WH_LD + j] * dd[j];
-            for (int k = r + 1; k < j; ++k) s += A[r * WH_LD + k] * A[j * WH_LD + k];
-            A[j * WH_LD + r] = -s * dd[r];
+        const double d = colk[par][k];
+        bad = bad || !(d > 0.0);
+        // 1 / d and 1 / sqrt(d) from the hardware estimates and two Newton steps each (to float64 rounding): the
+        // library division and square root are about a hundred instructions, per wave and step
+        double inv = __builtin_amdgcn_rcp(d), isq = __builtin_amdgcn_rsq(d);
+        inv = inv * fma(-d, inv, 2.0);
+        inv = inv * fma(-d, inv, 2.0);
+        isq = isq * fma(-0.5 * d * isq, isq, 1.5);
+        isq = isq * fma(-0.5 * d * isq, isq, 1.5);
+        // Only the live part is touched: rows > k, columns > k of the complement (a block column wholly at or left of
+        // k is skipped) and columns <= k of X (row k of X is zero to the right of k).  The branches are uniform.
+        double cc[WH_E], xc[WH_E];
+#pragma unroll
+        for (int b = 0; b < WH_E; ++b) {
+            cc[b] = colk[par][tx + WH_T * b];
+            xc[b] = rowx[par][tx + WH_T * b];
+        }
+#pragma unroll
+        for (int a = 0; a < WH_E; ++a) {
+            if (WH_T * a + WH_T - 1 < k) continue;               // every row of this block row is <= k - 1: retired
+            const int r = ty + WH_T * a;
+            const double cr = colk[par][r] * inv;
+            if (WH_T * a > k) {                                   // every row of the block row is > k
+#pragma unroll
+                for (int b = 0; b < WH_E; ++b) {
+                    if (WH_T * b + WH_T - 1 > k) S[a][b] -= cr * cc[b];
+                    if (WH_T * b <= k) X[a][b] -= cr * xc[b];
+                }
+            } else {                                              // the block row that holds row k
+#pragma unroll
+                for (int b = 0; b < WH_E; ++b) {
+                    if (r > k) {
+                        S[a][b] -= cr * cc[b];
+                        X[a][b] -= cr * xc[b];
+                    } else if (r == k) {
+                        X[a][b] = xc[b] * isq;
+                    }
+                }
+            }
         }
     }
+#pragma unroll
+    for (int a = 0; a < WH_E; ++a)
+#pragma unroll
+        for (int b = 0; b < WH_E; ++b) Xs[(ty + WH_T * a) * WH_LD + tx + WH_T * b] = X[a][b];
     __syncthreads();
-    auto rinv = [&](const int r, const int c) -> double {      // (R^-1)_rc
-        return r < c ? A[c * WH_LD + r] : r == c ? dd[r] : 0.0;
-    };
-    for (int e = tid; e < f * f; e += 1024) {
-        const int j = e / f, k = e % f;
-        B[e] = (float)rinv(k, j);                               // B[j][k] = (R^-1)_kj
-        double s = 0.0;
-        for (int m = (j > k ? j : k); m < f; ++m) s += rinv(j, m) * rinv(k, m);      // (G^-1)_jk = sum_m (R^-1)_jm (R^-1)_km
-        B[(f + j) * f + k] = (float)s;
+    // (G^-1)_rc = sum_m X_mr X_mc  (X lower triangular: the terms with m < max(r, c) are exact zeros); S is dead
+#pragma unroll
+    for (int a = 0; a < WH_E; ++a)
+#pragma unroll
+        for (int b = 0; b < WH_E; ++b) S[a][b] = 0.0;
+    for (int m = 0; m < f; ++m) {
+        double xr[WH_E], xc[WH_E];
+#pragma unroll
+        for (int a = 0; a < WH_E; ++a) xr[a] = Xs[m * WH_LD + ty + WH_T * a];
+#pragma unroll
+        for (int b = 0; b < WH_E; ++b) xc[b] = Xs[m * WH_LD + tx + WH_T * b];
+#pragma unroll
+        for (int a = 0; a < WH_E; ++a) {
+            if (WH_T * a > m) continue;                           // X_mr = 0 for r > m
+#pragma unroll
+            for (int b = 0; b < WH_E; ++b) S[a][b] += xr[a] * xc[b];
+        }
     }
-    if (tid == 0 && bad && info) atomicAdd(info, 1);
+#pragma unroll
+    for (int a = 0; a < WH_E; ++a)
+#pragma unroll
+        for (int b = 0; b < WH_E; ++b) {
+            const int r = ty + WH_T * a, c = tx + WH_T * b;
+            if (r < f && c < f) {
+                B[r * f + c] = (float)X[a][b];
+                B[(f + r) * f + c] = (float)S[a][b];
+            }
+        }
+    if (__syncthreads_or(bad) && tid == 0 && info) atomicAdd(info, 1);
 }
 
 template <int NB, int KS>
@@ -380,7 +442,7 @@ int32_t als_whiten_f32(const float *gram, float lamb, int32_t f, const float *Y,
     if (ws_bytes < als_whiten_workspace_bytes(f)) return als_fail_(ALS_ERR_WORKSPACE, "als_whiten_f32: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     float *B = (float *)(((uintptr_t)workspace + 255) / 256 * 256);
-    hipLaunchKernelGGL(whiten_factor_kernel, dim3(1), dim3(1024), 0, st, gram, lamb, f, B, info_out);
+    hipLaunchKernelGGL(whiten_factor_kernel, dim3(1), dim3(WH_T * WH_T), 0, st, gram, lamb, f, B, info_out);
     ALS_HIP_CHECK3(hipGetLastError());
     return als_scores_f32(Y, ldy, nullptr, n, B, f, 2 * (int64_t)f, f, WZ, ldw, stream);
 }
