@@ -96,11 +96,14 @@ def run_als_epoch(csr, X, Y, cache, alpha, absdiff=None, info=None, backend=ops,
 
 def short_rows_pay(n_short, n_rows, n_opp, f):
     """Whether a half-sweep should solve its short rows (at most ops.short_rows_max_entries(f) entries) in their
-    entry-space form.  The form needs the whitened table of the fixed factor - one GEMM over its n_opp rows per
-    half-sweep - so it pays when enough rows use it: at least a tenth of the rows and one for every 8 rows whitened.
-    n_opp >= 16 f keeps the Gram that is factored well away from rank deficiency.  All arguments are totals over the
-    whole matrix, so every rank of a sharded run decides alike and the factors do not depend on the sharding."""
-    return bool(ops.short_rows_max_entries(f) > 0 and n_opp >= 16 * f and n_short * 10 >= n_rows and n_short * 8 >= n_opp)
+    entry-space form.  The form needs the whitened table of the fixed factor - a factorisation of the Gram (0.2 ms)
+    and one GEMM over its n_opp rows (0.5 ms per million at f = 128) per half-sweep - and saves about 12 ns per
+    short row at f = 128: with a margin of two it pays from 32 768 + n_opp / 12 short rows on.  At f <= 64 the f x f
+    solve is cheap enough that the two come out even (measured on the 162 541 x 59 047 matrix: sweep -7 %, whitening
+    +7 %), so there the f x f form stays.  n_opp >= 16 f keeps the Gram that is factored well away from rank
+    deficiency.  All arguments are totals over the whole matrix, never a rank's share, so every rank of a sharded
+    run decides alike and the factors do not depend on the sharding."""
+    return bool(ops.short_rows_max_entries(f) > 0 and f > 64 and n_opp >= 16 * f and n_short >= 32768 + n_opp // 12)
 
 
 def _host_staged(T, group):

@@ -95,7 +95,11 @@ __global__ __launch_bounds__(64, short_waves(NB)) void short_rows_kernel(const S
     }
     const uint32_t ldu = (uint32_t)(p.ldw / 4);          // row pitch in 16-byte units
     const f32x4 *__restrict__ Wv = reinterpret_cast<const f32x4 *>(p.WZ);
+#ifdef ALS_ABLATE_PASS2_FROM_W      // timing-only build (wrong values): pass 2 re-reads the rows pass 1 fetched
+    const f32x4 *__restrict__ Zv = Wv;
+#else
     const f32x4 *__restrict__ Zv = Wv + p.f / 4;
+#endif
     // the lane's entries.  Stored zeros are dropped (ALS.py:79) and slots past the row's end are empty: both get
     // weight 0, an identity row in the matrix and t = 0; their loads go to the row's first entry's table row, so
     // nothing but rows the user touched is ever read.
