@@ -50,9 +50,9 @@ def parse():
     ap.add_argument("--factors", type=int, default=None)
     ap.add_argument("--solver", default="cholesky", choices=["cholesky", "cg"],
                     help="cholesky: exact solve (f <= 128, the default workload); cg: fixed-step conjugate gradient")
-    ap.add_argument("--cg-steps", type=int, default=10,
-                    help="conjugate-gradient steps per row (10: the count at which training metrics equal the exact "
-                         "solve's to 3 decimals on the small configuration; 3 is quoted beside it)")
+    ap.add_argument("--cg-steps", type=int, default=None,
+                    help="conjugate-gradient steps per row (default: max(10, ceil(f / 6)), the count at which training "
+                         "metrics equal the exact solve's to 3 decimals; 3 is quoted beside it)")
     ap.add_argument("--cg-form", default="auto", choices=["auto", "matrix", "lock_step"],
                     help="cg: on the formed matrix (one gather pass) or all rows in lock step (cg_steps+1 passes); "
                          "auto = matrix for f <= 128, lock_step above")
@@ -71,23 +71,26 @@ def parse():
 
 
 def build_shards(wl, world, rank, dev):
-    """This rank's shards of the weak-scaled matrix: (user CSR shard, item CSR shard, user bounds, item
-    bounds, N, M, nnz).  The matrix is `world` user blocks of wl["n_users"] users over the same items.
-    Block b holds wl["nnz"] entries, or - with wl["block_jitter"] - that many times 1 + jitter * (a
-    fixed pattern with zero mean), so that the blocks differ as real user populations do.  User shards
-    are the blocks themselves, or with wl["balance_users"] contiguous ranges with about equal entries."""
+    """This rank's shards of the matrix: (user CSR shard, item CSR shard, user bounds, item bounds, N, M, nnz).
+    The matrix is `blocks` user blocks of wl["n_users"] users over the same items: blocks = wl["blocks"] if the
+    workload fixes it (the same matrix for any number of GPUs: strong scaling), else `world` (one block per GPU: weak
+    scaling).  Block b holds wl["nnz"] entries, or - with wl["block_jitter"] and several blocks - that many times
+    1 + jitter * (a fixed pattern with zero mean), so that the blocks differ as real user populations do.  User
+    shards are contiguous ranges with about equal entries (wl["balance_users"], always when blocks != world), or the
+    blocks themselves."""
     from recommender_amd import data
     from recommender_amd.als import balanced_ranges
     nb, M = wl["n_users"], wl["n_items"]
-    N = nb * world
+    n_blocks = int(wl.get("blocks", world))
+    N = nb * n_blocks
     jit = float(wl.get("block_jitter", 0.0))
-    pattern = [((b * 5) % world) / max(world - 1, 1) * 2.0 - 1.0 for b in range(world)]      # a permutation of [-1, 1]
-    mean = sum(pattern) / world
+    pattern = [((b * 5) % n_blocks) / max(n_blocks - 1, 1) * 2.0 - 1.0 for b in range(n_blocks)]      # a permutation of [-1, 1]
+    mean = sum(pattern) / n_blocks
     item_counts = torch.zeros(M, dtype=torch.int64, device=dev)
     user_counts = []
     blocks = []
-    for b in range(world):
-        nnz_b = int(round(wl["nnz"] * (1.0 + jit * (pattern[b] - mean)))) if world > 1 else wl["nnz"]
+    for b in range(n_blocks):
+        nnz_b = int(round(wl["nnz"] * (1.0 + jit * (pattern[b] - mean)))) if n_blocks > 1 else wl["nnz"]
         keys, r = data.synth_pairs(nb, M, nnz_b, seed=1234 + b, device=dev, item_seed=1234)
         u = torch.div(keys, M, rounding_mode="floor"); i = keys - u * M
         item_counts += torch.bincount(i, minlength=M)
@@ -97,7 +100,7 @@ def build_shards(wl, world, rank, dev):
     item_ptr = np.zeros(M + 1, dtype=np.int64)
     np.cumsum(item_counts.cpu().numpy(), out=item_ptr[1:])
     ib = balanced_ranges(item_ptr, world)
-    if wl.get("balance_users") and world > 1:
+    if (wl.get("balance_users") and world > 1) or n_blocks != world:
         user_ptr = np.zeros(N + 1, dtype=np.int64)
         np.cumsum(torch.cat(user_counts).cpu().numpy(), out=user_ptr[1:])
         ub = [int(x) for x in balanced_ranges(user_ptr, world)]
@@ -220,11 +223,14 @@ def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel,
         Y = torch.from_numpy(Yh.astype(np.float32)).to(dev)
     if f > 128:
         solver = "cg"
+    if cg_steps is None:
+        from recommender_amd.als import default_cg_steps
+        cg_steps = default_cg_steps(f)
     csr_u = ops.DeviceCSR(U[0], U[1], U[2], (ub[rank + 1] - ub[rank], M), dev)
     # with N user blocks an item row is N times longer: longer chunks keep the partial-sum traffic of the
     # split rows (11 KB per chunk at f=64) small against the gather
     csr_i = ops.DeviceCSR(Ut[0], Ut[1], Ut[2], (ib[rank + 1] - ib[rank], N), dev,
-                          chunk_nnz=2048 * (1 if world == 1 else 4))
+                          chunk_nnz=2048 * (1 if int(wl.get("blocks", world)) == 1 else 4))
     eng = ALSEngine(csr_u, csr_i, X, Y, wl["lamb"], wl["alpha"], ub, ib, group, solver=solver,
                     cg_steps=cg_steps, cg_form=cg_form, short_rows={"auto": "auto", "on": True, "off": False}[short_rows]
                     if solver != "cg" else False)
@@ -255,6 +261,8 @@ def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel,
         return ops.sweep_opts(tap=(e0, e1), **base_opts)
 
     eng.sweep_opts = tapped
+    if world > 1:
+        eng.exchange_taps = {"x_wait": [], "y_gather": []}
     sync()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -262,6 +270,16 @@ def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel,
     sync()
     dt = time.perf_counter() - t0
     eng.sweep_opts = None
+    exposed = None
+    if world > 1:
+        # what the main stream spends waiting for exchanges per step: the part of the user exchange still in flight
+        # when the user sweep is queued, and the item exchange (nothing overlaps it); max over ranks
+        mine = [sum(a.elapsed_time(b) for a, b in eng.exchange_taps[k]) / steps for k in ("x_wait", "y_gather")]
+        t = torch.tensor(mine, dtype=torch.float64, device="cpu" if ctx.rehearsal else dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        exposed = {"user_exchange_wait_ms": float(t[0]), "item_exchange_ms": float(t[1]),
+                   "exposed_exchange_ms": float(t[0] + t[1]), "note": "max over ranks, per iteration"}
+        eng.exchange_taps = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if ctx.rehearsal else dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -290,7 +308,7 @@ def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel,
                     % (workload, N, M, nnz, f, wl["lamb"], wl["alpha"],
                        "%d conjugate-gradient steps per row (%s)" % (cg_steps, "lock step" if lockstep else "formed matrix")
                        if cg else "exact Cholesky solve, %s accumulate" % accumulate),
-        "nnz": nnz, "f": f, "solver": solver, "steps": steps, "seconds": dt,
+        "nnz": nnz, "f": f, "solver": solver, "cg_steps": cg_steps if cg else None, "steps": steps, "seconds": dt,
         "value": 2.0 * nnz * steps / dt, "ms_per_step": dt / steps * 1e3,
         "kernel": ("cg half-sweep (cg_items_kernel passes + Gram GEMM)" if lockstep else
                    "per-row kernels of the half-sweep (%s: gather/accumulate + %s; the long rows' combine and solve "
@@ -304,6 +322,10 @@ def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel,
         "user_rows": csr_u.shape[0], "item_rows": csr_i.shape[0],
         "short_rows": short_rows_note(short, csr_u, csr_i, f),
     }
+    if exposed is not None:
+        res["exchange"] = exposed
+    if "blocks" in wl:
+        res["scaling"] = strong_scaling(workload, f, solver, world, dt / steps * 1e3)
     if not cg:
         fl = algorithmic_flops(csr_u.nnz, csr_u.shape[0], f) + algorithmic_flops(csr_i.nnz, csr_i.shape[0], f)
         res["mfma"] = mfma_view(fl / 2, (bytes_u + bytes_i) / 2, (ku + ki) / 2)
@@ -320,6 +342,24 @@ def short_rows_note(short, csr_u, csr_i, f):
     for which, csr in (("users", csr_u), ("items", csr_i)):
         n = int(csr.short_bounds[-1] - csr.short_bounds[nb]) if lim else 0
         out[which] = {"entry_space_form": bool(short.get(which)), "rows_within_limit": n, "rows": csr.shape[0]}
+    return out
+
+
+def strong_scaling(workload, f, solver, world, ms_per_step):
+    """A workload of fixed size (wl["blocks"]) is the same matrix for any number of GPUs: efficiency = T_1 / (g T_g).
+    On one GPU this run IS T_1; on g > 1 GPUs T_1 comes from the single-GPU measurement kept under profiles/
+    (profiles/scaling_t1.json, written from a --gpus 1 run of the same workload), or is unknown."""
+    out = {"kind": "strong", "gpus": world, "ms_per_step": ms_per_step}
+    if world == 1:
+        out.update(T1_ms=ms_per_step, T1_source="this run", efficiency=1.0)
+        return out
+    key = "%s_f%d_%s" % (workload, f, solver)
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "scaling_t1.json")))[key]
+        out.update(T1_ms=rec["ms_per_step"], T1_source="profiles/scaling_t1.json[%s] (%s)" % (key, rec.get("source", "")),
+                   efficiency=rec["ms_per_step"] / (world * ms_per_step))
+    except Exception:
+        out.update(T1_ms=None, T1_source="no single-GPU measurement of %s on record" % key, efficiency=None)
     return out
 
 
@@ -346,6 +386,9 @@ def measure_rank_share(ctx, wl_name, solver, cg_steps, accumulate, row_kernel, s
     wl = dict(data.WORKLOADS[wl_name])
     W, nb, M, f = wl["of_world"], wl["n_users"], wl["n_items"], wl["f"]
     N, mi = nb * W, M // W
+    if cg_steps is None:
+        from recommender_amd.als import default_cg_steps
+        cg_steps = default_cg_steps(f)
     if state is None:
         keys, r = data.synth_pairs(nb, M, wl["nnz"], seed=1234, device=dev, item_seed=1234)
         U = data.csr_from_sorted_keys(keys, r, nb, M)
@@ -506,24 +549,29 @@ def main():
         plan = []
         if args.workload == "c2_ml25m_syn" and not args.factors and args.solver == "cholesky":
             plan.append(("c2_ml25m_syn", 128, "cholesky", shards, 0))
-            plan.append(("c2_ml25m_syn", 128, "cg", shards, args.cg_steps))
+            plan.append(("c2_ml25m_syn", 128, "cg", shards, -1))           # -1: the default count for this f
             plan.append(("c3_shard_syn", None, "cholesky", None, 0))
-            plan.append(("c3_shard_syn", None, "cg", "prev", args.cg_steps))
+            plan.append(("c3_shard_syn", None, "cg", "prev", -1))
             plan.append(("c3_shard_syn", None, "cg", "prev", 3))       # the truncation other ALS libraries default to
+            # the whole 1 B-entry matrix: T_1 on one GPU, the strong-scaled run on several
+            plan.append(("c3_full_syn", None, "cholesky", None, 0))
         prev = None
         for (wname, ff, solver, sh, cgs) in plan:
             try:
-                r, prev, _ = measure(ctx, wname, ff, solver, cgs or args.cg_steps, "auto", args.accumulate, args.row_kernel,
+                r, prev, _ = measure(ctx, wname, ff, solver, cgs if cgs > 0 else args.cg_steps, "auto", args.accumulate, args.row_kernel,
                                      args.also_steps, 1, shards=prev if sh == "prev" else sh, short_rows=args.short_rows)
-                also.append({"workload": r["workload"], "f": r["f"], "solver": r["solver"], "cg_steps": cgs or None,
+                also.append({"workload": r["workload"], "f": r["f"], "solver": r["solver"], "cg_steps": r["cg_steps"],
                              "steps": r["steps"],
                              "nnz_per_s": r["value"], "ms_per_step": r["ms_per_step"], "launch_ms": r["launch_ms"],
                              "achieved_GBs": r["achieved"], "frac": r["achieved"] / HBM_PEAK_GBS,
                              "algorithmic_bytes_per_launch": r["bytes_per_launch"], "kernel": r["kernel"],
                              "traffic": pmc_traffic("%s_f%d%s" % (wname, r["f"], "" if solver != "cg" else
-                                                                  "_cg" if cgs == args.cg_steps else "_cg%d" % cgs)),
+                                                                  "_cg" if cgs <= 0 else "_cg%d" % cgs)),
                              "rows_this_rank": {"user": r["user_rows"], "item": r["item_rows"]},
                              "short_rows": r["short_rows"]})
+                for k in ("exchange", "scaling"):
+                    if k in r:
+                        also[-1][k] = r[k]
                 if "mfma" in r:
                     also[-1]["mfma"] = r["mfma"]
             except Exception as exc:            # a failing extra point must not cost the headline line
@@ -536,7 +584,7 @@ def main():
             prev = None                     # drops the last reference to the c3 shards
             torch.cuda.empty_cache()
             state = None
-            for (solver, cgs) in (("cholesky", 0), ("cg", args.cg_steps)):
+            for (solver, cgs) in (("cholesky", 0), ("cg", args.cg_steps)):        # None: the default count for f
                 try:
                     r, state = measure_rank_share(ctx, "c3_rank_syn", solver, cgs, args.accumulate, args.row_kernel,
                                                   args.also_steps, 1, state, short_rows=args.short_rows)
@@ -579,6 +627,9 @@ def main():
         out["roofline"]["short_rows"] = head["short_rows"]
         if world > 1:
             out["distributed"] = {"backend": backend, "world_size": torch.distributed.get_world_size(), "ranks": ranks}
+        for k in ("exchange", "scaling"):
+            if k in head:
+                out[k if k == "exchange" else "strong_scaling"] = head[k]
         if also:
             out["also"] = also
         if world == 1 and not args.no_cpu_baseline and Xh is not None:

@@ -94,6 +94,16 @@ def run_als_epoch(csr, X, Y, cache, alpha, absdiff=None, info=None, backend=ops,
     return backend.half_sweep(csr, Y, cache, X, alpha, absdiff=absdiff, info=info, opts=opts)
 
 
+def default_cg_steps(f):
+    """Conjugate-gradient steps per row and half-sweep at which 15 iterations give the exact solve's MAP@200,
+    precision@10 and held-out RMSE to 3 decimals: max(10, ceil(f / 6)).  Pinned at f = 20 (10 steps; 8 miss
+    precision@10), f = 128 (22; 16 miss precision@10 by 1.6e-3, 18 hold) and f = 256 (43; 36 miss it by 6e-4, 42 hold)
+    by the metric-level tests of tests/test_gpu_recommender.py; the truncated iteration needs about f / 6 steps
+    whatever the preconditioning (with the Gram's Cholesky factor as preconditioner 8 steps reach the accuracy of 10
+    plain ones at f = 128: not worth a second factor table)."""
+    return max(10, -(-int(f) // 6))
+
+
 def short_rows_pay(n_short, n_rows, n_opp, f):
     """Whether a half-sweep should solve its short rows (at most ops.short_rows_max_entries(f) entries) in their
     entry-space form.  The form needs the whitened table of the fixed factor - a factorisation of the Gram (0.2 ms)
@@ -211,7 +221,7 @@ class ALSEngine:
     """
 
     def __init__(self, csr_users, csr_items, X, Y, lamb, alpha, user_bounds=None, item_bounds=None, group=None,
-                 backend=ops, overlap_chunks=None, solver="auto", cg_steps=10, cg_form="auto", short_rows="auto",
+                 backend=ops, overlap_chunks=None, solver="auto", cg_steps=None, cg_form="auto", short_rows="auto",
                  uneven_exchange="padded"):
         self.group = group
         if uneven_exchange not in UNEVEN_FORMS:
@@ -246,6 +256,8 @@ class ALSEngine:
         if solver == "cholesky" and self.f > _lib.MAX_FACTORS_EXACT:
             raise ValueError("the exact solve supports f <= %d; use solver='cg'" % _lib.MAX_FACTORS_EXACT)
         self.solver = solver
+        if cg_steps is None:
+            cg_steps = default_cg_steps(self.f)
         self.cg_steps = int(cg_steps) if solver == "cg" else 0
         if solver == "cg" and self.cg_steps < 1:
             raise ValueError("cg_steps must be >= 1")
@@ -269,6 +281,9 @@ class ALSEngine:
         self.overlap_chunks = max(1, int(overlap_chunks))      # the same on every rank
         self._user_parts = None
         self._side = None
+        # benchmarks set this to {"x_wait": [], "y_gather": []}: per step, event pairs around the main stream's wait for
+        # the user exchange still in flight when the user sweep has been queued, and around the item exchange
+        self.exchange_taps = None
 
     def _decide_short_rows(self, mode):
         off = {"users": False, "items": False}
@@ -334,12 +349,26 @@ class ALSEngine:
                     done.append(self._side.record_event())
             else:
                 _all_gather_row_blocks(self.X, starts, sizes, self.rank, self.group, self.uneven_exchange)
+        tap = self._tap_begin("x_wait") if self.world > 1 else None
         for ev in done:
             torch.cuda.current_stream(self.X.device).wait_event(ev)
         if len(parts) > 1:
             torch.sum(torch.cat([p[3] for p in parts]), 0, keepdim=True, out=self._dX)
         if self.world > 1 and not chunked:
             _all_gather_rows(self.X[: self.n_users], self.user_bounds, self.rank, self.group, self.uneven_exchange)
+        self._tap_end(tap)
+
+    def _tap_begin(self, which):
+        if self.exchange_taps is None or not self.X.is_cuda:
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.exchange_taps[which].append((e0, e1))
+        return e1
+
+    def _tap_end(self, e1):
+        if e1 is not None:
+            e1.record()
 
     # one ALS iteration = X half-sweep + Y half-sweep, Gram refreshes included
     def step(self):
@@ -356,7 +385,9 @@ class ALSEngine:
                           self.backend, self.cg_steps, self.cg_form, self.sweep_opts("items") if self.sweep_opts else None,
                           self.short["items"])
         if self.world > 1:
+            tap = self._tap_begin("y_gather")
             _all_gather_rows(self.Y[: self.n_items], self.item_bounds, self.rank, self.group, self.uneven_exchange)
+            self._tap_end(tap)
 
     def last_delta(self):
         """mean|dX| + mean|dY| of the last step, as ALSRef.train's trace (ALS.py:136-139).

@@ -95,6 +95,14 @@ WORKLOADS = {
     # stored entries (balance_users), not at the block boundaries: ranks own different numbers of rows.
     "c3_shard_syn": dict(n_users=1250000, n_items=1000000, nnz=125000000, f=128, lamb=0.01, alpha=40.0, iters=15,
                          init="device", block_jitter=0.1, balance_users=True),
+    # the whole 10 M x 1 M, 1 B-entry matrix (8 such blocks, entry counts jittered +-10 %), whatever the number of GPUs:
+    # on one GPU it is T_1 of the strong-scaling efficiency T_1 / (g T_g); on g GPUs users and items are cut into g
+    # shards of about equal stored entries
+    "c3_full_syn": dict(n_users=1250000, n_items=1000000, nnz=125000000, f=128, lamb=0.01, alpha=40.0, iters=15,
+                        init="device", block_jitter=0.1, balance_users=True, blocks=8),
+    # the same construction a hundred times smaller (tests and one-GPU rehearsals of the strong-scaled run)
+    "c3_full_small_syn": dict(n_users=12500, n_items=10000, nnz=1250000, f=128, lamb=0.01, alpha=40.0, iters=15,
+                              init="device", block_jitter=0.1, balance_users=True, blocks=8),
     # what one rank of the eight-GPU run of that matrix executes: its 1.25 M users over all 1 M items, and its
     # 125 000 items over all 10 M users (item rows eight times longer, the whole 5 GB user table gathered from)
     "c3_rank_syn": dict(n_users=1250000, n_items=1000000, nnz=125000000, f=128, lamb=0.01, alpha=40.0, of_world=8),

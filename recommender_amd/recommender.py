@@ -31,9 +31,9 @@ DEFAULTS = dict(f=20,           # ALS.json.template:26 (the reference's layer wi
                                     # that still enter the Gram (ALS.py:243, ALS.py:456)
                 chunk_nnz=2048,
                 solver="auto",      # "cholesky" (exact, f <= 128), "cg", or "auto" = exact where it exists
-                cg_steps=10,        # conjugate-gradient steps per row and half-sweep when solver is "cg": the count
-                                    # at which 15 iterations give the exact solve's MAP@200 / precision@10 / RMSE
-                                    # to 3 decimals on the ml-latest-small-shaped configuration (3 and 6 do not)
+                cg_steps=None,      # conjugate-gradient steps per row and half-sweep when solver is "cg"; None =
+                                    # als.default_cg_steps(f) = max(10, ceil(f / 6)), the count at which 15 iterations
+                                    # give the exact solve's MAP@200 / precision@10 / RMSE to 3 decimals
                 short_rows="auto",  # exact solver: rows with fewer ratings than factors solved in their entry-space form
                                     # ("auto": where it pays, als.short_rows_pay; True / False)
                 med_score=3.0,      # ALS.py:402
@@ -302,7 +302,7 @@ class RecommenderALS:
         f = self.X.shape[1]
         if self.config["solver"] == "cg" or f > 128:
             # a brand-new row starts far from its solution: f steps reach it to rounding
-            ops.half_sweep_cg(csr, self.Y, cache, self.X, self.config["alpha"], max(f, self.config["cg_steps"]), info=info)
+            ops.half_sweep_cg(csr, self.Y, cache, self.X, self.config["alpha"], max(f, self.config["cg_steps"] or 0), info=info)
         else:
             ops.half_sweep(csr, self.Y, cache, self.X, self.config["alpha"], info=info)
         if int(info.item()):

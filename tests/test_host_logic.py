@@ -179,3 +179,30 @@ def test_every_stream_lookup_sits_inside_a_device_guard():
                 guarded = True
                 break
         assert guarded, "ops.py:%d: _stream() outside `with torch.cuda.device(...)`" % call.lineno
+
+
+def test_strong_scaling_shards_tile_the_one_matrix():
+    """bench.py's fixed-size workloads (wl["blocks"]) are the same matrix for any number of GPUs: the user and item
+    shards of 2 and 3 ranks, cut by stored entries, concatenate to the single-rank CSR bit for bit, and no shard
+    holds much more than its share of the entries."""
+    import importlib.util
+    import torch
+    from recommender_amd import data
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    wl = dict(data.WORKLOADS["c3_full_small_syn"], n_users=500, n_items=300, nnz=6000, blocks=4)
+    U1, Ut1, ub1, ib1, N, M, nnz = bench.build_shards(wl, 1, 0, torch.device("cpu"))
+    assert (N, M) == (2000, 300) and ub1 == [0, N] and ib1 == [0, M] and int(U1[0][-1]) == nnz == int(Ut1[0][-1])
+    for world in (2, 3):
+        parts = [bench.build_shards(wl, world, r, torch.device("cpu")) for r in range(world)]
+        ub, ib = parts[0][2], parts[0][3]
+        assert all(p[2] == ub and p[3] == ib and p[4:] == (N, M, nnz) for p in parts)
+        assert ub[0] == 0 and ub[-1] == N and ib[0] == 0 and ib[-1] == M
+        for side, whole, bounds in ((0, U1, ub), (1, Ut1, ib)):
+            ptr = torch.cat([torch.zeros(1, dtype=torch.int64)] +
+                            [p[side][0][1:] + int(whole[0][bounds[r]]) for r, p in enumerate(parts)])
+            assert torch.equal(ptr, whole[0])
+            assert torch.equal(torch.cat([p[side][1] for p in parts]), whole[1])
+            assert torch.equal(torch.cat([p[side][2] for p in parts]), whole[2])
+            share = [int(whole[0][bounds[r + 1]] - whole[0][bounds[r]]) for r in range(world)]
+            assert max(share) < 1.25 * nnz / world, share
