@@ -312,7 +312,8 @@ __device__ __forceinline__ void accumulate_range(f32x4 (&acc)[Geo<VW>::NT], floa
             const int cc = col[ii];
             const float rr = val[ii];
             const float ww = alpha * rr;
-            off = ok ? (uint32_t)cc * ldu : 0u;
+            off = (uint32_t)cc * ldu;      // a lane past the end gathers the range's first entry's row (ii = s) with weight 0:
+                                           // only rows this CSR row references are ever read
             w = ok ? (SPLIT ? __builtin_sqrtf(ww) : ww) : 0.f;      // SPLIT: both operands carry sqrt(w)
             cw = (ok && rr != 0.f) ? 1.f + ww : 0.f;
         } else {

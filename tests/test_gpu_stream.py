@@ -163,3 +163,38 @@ def test_stream_rejects_what_it_cannot_run():
     csr = ra.DeviceCSR(ptr, ind, dat, (200, 300), "cuda")
     with pytest.raises(ValueError, match="STREAM"):
         ra.half_sweep(csr, Y, ra.gram(Y, 0.1), X, 40.0, opts=ra.ops.sweep_opts(row_kernel="stream", accumulate="fp32"))
+
+
+@pytest.mark.parametrize("f", [64, 128])
+def test_a_non_finite_row_nobody_references_changes_nothing(f):
+    """Lanes past a row's (or a 32-entry block's) end gather SOME factor row with weight 0.  That row must be one the
+    CSR row references itself: with factor row 0 set to NaN and no CSR row touching item 0, every kernel (one wave per
+    row, the stream kernel, the short-row form) must return what it returns for a finite row 0, bit for bit."""
+    import recommender_amd as ra
+    rng = np.random.default_rng(31 + f)
+    n_rows, n_cols, lamb, alpha = 700, 3000, 0.01, 40.0
+    lens = rng.integers(0, 200, size=n_rows); lens[:3] = [1, 33, 2500]
+    ptr = np.zeros(n_rows + 1, dtype=np.int64); np.cumsum(lens, out=ptr[1:])
+    col = np.concatenate([np.sort(rng.choice(np.arange(1, n_cols), size=int(L), replace=False)) for L in lens]).astype(np.int32)
+    val = (rng.integers(1, 11, size=col.shape[0]) * 0.5).astype(np.float32)
+    Y = rng.normal(0, 1 / np.sqrt(f), size=(n_cols, f)).astype(np.float32)
+    X0 = rng.normal(0, 1 / np.sqrt(f), size=(n_rows, f)).astype(np.float32)
+    csr = ra.DeviceCSR(ptr, col, val, (n_rows, n_cols), "cuda")
+
+    def run(y0, **kw):
+        Yd = torch.from_numpy(Y).cuda(); Yd[0] = y0
+        Xd = torch.from_numpy(X0).cuda()
+        gc = ra.gram(Yd[1:], lamb)                   # the Gram of the rows that exist (row 0 is nobody's)
+        short = kw.pop("short", False)
+        if short:
+            ra.whiten(Yd[1:], gc)
+            gc.whitened = torch.cat([torch.full_like(gc.whitened[:1], float("nan")), gc.whitened], 0)
+        ra.half_sweep(csr, Yd, gc, Xd, alpha, opts=ra.ops.sweep_opts(**kw) if kw else None, short_rows=short)
+        torch.cuda.synchronize()
+        return Xd.cpu().numpy()
+
+    kinds = [dict(row_kernel="wave")] + ([dict(row_kernel="stream"), dict(short=True)] if f == 128 else [])
+    for kw in kinds:
+        finite, nan = run(0.25, **dict(kw)), run(float("nan"), **dict(kw))
+        assert np.all(np.isfinite(nan)), kw
+        assert np.array_equal(finite, nan), kw

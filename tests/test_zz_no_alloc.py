@@ -80,3 +80,47 @@ def test_static_scratch_rejects_what_does_not_fit(ra):
     msg = lib.als_last_error_string().decode()
     assert "scratch" in msg and str(limit) in msg
     del ptr
+
+
+def test_static_call_allocates_nothing_and_replays_from_a_graph(ra):
+    """What the entry point exists for: the call leaves the device's free memory and torch's allocator untouched, and
+    it can be recorded into a HIP graph (no allocation, no synchronisation inside) whose replay returns the eager
+    call's bits."""
+    from recommender_amd._lib import lib
+    rng = np.random.default_rng(77)
+    N, M, f = 900, 1500, 128
+    ptr, ind, dat = _matrix(rng, N, M, 30, 600)
+    X0 = torch.from_numpy(rng.normal(0, 1 / np.sqrt(f), size=(N, f)).astype(np.float32)).cuda()
+    Y = torch.from_numpy(rng.normal(0, 1 / np.sqrt(f), size=(M, f)).astype(np.float32)).cuda()
+    csr = ra.DeviceCSR(ptr, ind, dat, (N, M), "cuda", chunk_nnz=128)
+    gc = ra.gram(Y, 0.01)
+    assert lib.als_static_scratch_init() == 0
+    d = torch.zeros(1, dtype=torch.float64, device="cuda")
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    X = X0.clone()
+    ra.half_sweep(csr, Y, gc, X, 40.0, absdiff=d, info=info, static_scratch=True)        # first use on this device done
+    torch.cuda.synchronize()
+    eager, eager_d = X.clone(), float(d.item())
+    X.copy_(X0)
+    torch.cuda.synchronize()
+    free0, alloc0, reserved0 = torch.cuda.mem_get_info()[0], torch.cuda.memory_allocated(), torch.cuda.memory_reserved()
+    ra.half_sweep(csr, Y, gc, X, 40.0, absdiff=d, info=info, static_scratch=True)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0
+    assert torch.cuda.memory_allocated() == alloc0 and torch.cuda.memory_reserved() == reserved0
+    assert torch.equal(X, eager) and float(d.item()) == eager_d
+    # recorded once, replayed twice from the initial factors
+    X.copy_(X0)
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            ra.half_sweep(csr, Y, gc, X, 40.0, absdiff=d, info=info, static_scratch=True)
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(2):
+        X.copy_(X0); d.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(X, eager) and float(d.item()) == eager_d
+    assert int(info.item()) == 0
