@@ -327,8 +327,9 @@ int32_t als_topk_rows_f32(float *scores, int64_t lds, int64_t n_rows, int64_t M,
  * rows, row u for output row u.  ex_by_user_id != 0: it is indexed by user id - output row u reads row
  * user_ids[u] - so the training matrix's own rowptr/col serve as they lie on the device, for any block of users
  * (the "drop rated items" filter of RecommenderService.py:16-29 with nothing built per request).
- * overflow_out [device] one int32: number of candidates that did not fit a user's list; if it is
- * not 0 the outputs are not valid and the caller must use the two-call path for these users.
+ * overflow_out [device] one int32: number of candidates that did not fit a user's list.  If it is not 0, the
+ * users it happened to (and only they) have item -1 in every slot of their idx_out row and the caller must use the
+ * two-call path for them; every other row is valid.
  * 1 <= k <= min(1024, M); nu <= 65535*64. */
 size_t als_recommend_topk_workspace_bytes(int64_t nu, int64_t M, int32_t k);
 int32_t als_recommend_topk_f32(const float *X, int64_t ldx, const int64_t *user_ids, int64_t nu, const float *Y,

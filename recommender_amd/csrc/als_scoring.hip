@@ -586,6 +586,23 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(const CandArgs c
     const int cap = c.cap, k = c.k;
     const int tid = threadIdx.x;
     const int64_t row = blockIdx.x;
+    // A user whose candidates did not fit the row in some range (count > cap: e.g. thousands of excluded items that
+    // all score above the threshold) is given up HERE, alone: its threshold becomes +inf, so that later ranges add
+    // nothing to it, and its output row is item -1 throughout - the caller redoes such users by the two-call path.
+    const bool dead = count[row] > cap || citem[row * cap] < 0;
+    if (dead) {
+        for (int q = tid; q < k; q += 256) {
+            if (idx_out) {
+                idx_out[row * k + q] = -1;
+                score_out[row * k + q] = -__builtin_inff();
+            } else {
+                citem[row * cap + q] = -1;
+                cscore[row * cap + q] = __builtin_inff();
+            }
+        }
+        if (tid == 0) count[row] = k;
+        return;
+    }
     const int n = min(count[row], cap);
     int n2 = 1;
     while (n2 < n) n2 <<= 1;

@@ -586,8 +586,9 @@ def recommend_topk(X, Y, users, k, M=None, exclude_csr=None, block_users=4096, f
     index it by user id; nothing is built per block.  Returns (idx int32 [nu, k], scores [nu, k]).
 
     fused=True: als_recommend_topk_f32 - only the first 16 384+ items of a block are materialised,
-    the rest is filtered in the score kernel's registers.  A block whose candidate lists overflow
-    (reported by the library) is redone by the two-call path, as is everything when fused=False."""
+    the rest is filtered in the score kernel's registers.  Users whose candidate list overflows (the library marks
+    their rows: e.g. thousands of excluded items that all score near the top) are redone by the two-call path - they
+    alone, not their block -, as is everyone when fused=False."""
     ldx = _factor_ld(X, "X"); ldy = _factor_ld(Y, "Y")
     M = Y.shape[0] if M is None else int(M)
     f = X.shape[1]
@@ -611,7 +612,7 @@ def recommend_topk(X, Y, users, k, M=None, exclude_csr=None, block_users=4096, f
     bu = min(block_users, max(nu, 1))
     buf = None
     blocks = [(s, min(nu, s + block_users)) for s in range(0, nu, block_users)]
-    redo = list(range(len(blocks)))
+    redo = None                     # positions (rows of the output) to be done by the two-call path; None = all
     if fused and blocks:
         ws = torch.empty(lib.als_recommend_topk_workspace_bytes(bu, M, k), dtype=torch.uint8, device=X.device)
         overflow = torch.zeros(len(blocks), dtype=torch.int32, device=X.device)
@@ -621,15 +622,22 @@ def recommend_topk(X, Y, users, k, M=None, exclude_csr=None, block_users=4096, f
                                                  _ptr(ex[0]) if ex else None, _ptr(ex[1]) if ex else None, 1,
                                                  _ptr(idx[s:e]), _ptr(val[s:e]), _ptr(overflow[b:b + 1]), _ptr(ws),
                                                  ws.numel(), _stream()), "als_recommend_topk_f32")
-        redo = torch.nonzero(overflow).flatten().cpu().tolist()       # one synchronisation for all blocks
+        # users whose candidate list overflowed (marked with item -1) are redone, the others stand; one
+        # synchronisation for all blocks
+        redo = torch.nonzero(idx[:, 0] < 0).flatten() if bool(overflow.any()) else idx.new_zeros(0, dtype=torch.int64)
     # the materialised path works on row blocks whose score matrix stays below 4 GiB
     rows_per = max(1, min(bu, (1 << 30) // M))
-    for b in redo:
-        for s in range(blocks[b][0], blocks[b][1], rows_per):
-            e = min(blocks[b][1], s + rows_per)
-            if buf is None:
-                buf = torch.empty((rows_per, M), dtype=torch.float32, device=X.device)
-            sc = scores(X, Y, users[s:e], M, out=buf)
-            i_, v_ = topk_rows(sc, k, ex, users[s:e] if ex else None)
+    n_redo = nu if redo is None else int(redo.numel())
+    for s in range(0, n_redo, rows_per):
+        e = min(n_redo, s + rows_per)
+        pos = None if redo is None else redo[s:e]
+        us = users[s:e] if pos is None else users[pos].contiguous()
+        if buf is None:
+            buf = torch.empty((min(rows_per, n_redo), M), dtype=torch.float32, device=X.device)
+        sc = scores(X, Y, us, M, out=buf)
+        i_, v_ = topk_rows(sc, k, ex, us if ex else None)
+        if pos is None:
             idx[s:e] = i_; val[s:e] = v_
+        else:
+            idx[pos] = i_; val[pos] = v_
     return idx, val

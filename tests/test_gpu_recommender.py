@@ -586,6 +586,46 @@ def test_fused_topk_overflow_falls_back(ra):
     assert torch.equal(i0, i1) and torch.equal(v0, v1)
 
 
+def test_heavy_users_overflow_alone(ra):
+    """Users whose excluded (rated) items are exactly their best-scoring ones, 20 000 of them: every such item of a
+    later range beats the threshold and takes a candidate slot before it is dropped, so these users' lists overflow.
+    They alone are redone by the two-call path (the library marks their rows); their neighbours in the same block
+    keep the fused result, and everything equals the two-call path bit for bit."""
+    rng = np.random.default_rng(12)
+    nu, M, f, k = 300, 100000, 64, 100
+    Xh = rng.normal(size=(nu, f)).astype(np.float32); Yh = rng.normal(size=(M, f)).astype(np.float32)
+    X = torch.from_numpy(Xh).cuda(); Y = torch.from_numpy(Yh).cuda()
+    heavy = [7, 150, 299]
+    rows = [np.sort(rng.choice(M, size=int(c), replace=False)).astype(np.int32) for c in rng.integers(0, 200, size=nu)]
+    for u in heavy:
+        sc = Yh.astype(np.float64) @ Xh[u].astype(np.float64)
+        rows[u] = np.sort(np.argsort(-sc)[:20000]).astype(np.int32)
+    ptr = np.zeros(nu + 1, dtype=np.int64); np.cumsum([len(r) for r in rows], out=ptr[1:])
+    ex = (ptr, np.concatenate(rows))
+    users = torch.arange(nu, device="cuda")
+    from recommender_amd._lib import lib
+    # the library call itself: an overflow count, the three heavy rows marked with item -1, every other row final
+    ws = torch.empty(lib.als_recommend_topk_workspace_bytes(nu, M, k), dtype=torch.uint8, device="cuda")
+    dex = ra.ops.device_exclusions(ex, "cuda")
+    idx = torch.empty((nu, k), dtype=torch.int32, device="cuda"); val = torch.empty((nu, k), dtype=torch.float32, device="cuda")
+    over = torch.zeros(1, dtype=torch.int32, device="cuda")
+    rc = lib.als_recommend_topk_f32(X.data_ptr(), f, users.data_ptr(), nu, Y.data_ptr(), f, M, f, k, dex[0].data_ptr(),
+                                    dex[1].data_ptr(), 1, idx.data_ptr(), val.data_ptr(), over.data_ptr(), ws.data_ptr(),
+                                    ws.numel(), None)
+    torch.cuda.synchronize()
+    assert rc == 0 and int(over.item()) > 0
+    marked = torch.nonzero(idx[:, 0] < 0).flatten().cpu().tolist()
+    assert marked == heavy and bool((idx[heavy] == -1).all())
+    j0, w0 = _two_call(ra, X, Y, users, k, ex)
+    keep = [u for u in range(nu) if u not in heavy]
+    assert torch.equal(idx[keep], j0[keep]) and torch.equal(val[keep], w0[keep])
+    # the wrapper redoes the marked users only and returns the two-call result for everyone
+    j1, w1 = ra.ops.recommend_topk(X, Y, users, k, exclude_csr=ex)
+    assert torch.equal(j0, j1) and torch.equal(w0, w1)
+    for u in heavy:
+        assert not np.intersect1d(j1[u].cpu().numpy(), rows[u]).size
+
+
 def test_device_transpose_equals_scipy(ra):
     rng = np.random.default_rng(2)
     U = sps.random(300, 170, density=0.05, random_state=7, format="csr", dtype=np.float64)
