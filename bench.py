@@ -32,6 +32,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak
 MFMA_F32_PEAK_TFLOPS = 157.3      # dense float32 matrix-core peak (256 CUs x 256 flops per cycle x 2.4 GHz)
+MFMA_BF16_PEAK_TFLOPS = 2500.0    # dense bf16 matrix-core peak
+SIMDS, CLOCK_HZ = 1024, 2.4e9     # 256 CUs x 4 SIMDs, each with one matrix pipe; peak engine clock
 
 
 def algorithmic_flops(nnz, rows, f):
@@ -329,6 +331,8 @@ def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel,
     if not cg:
         fl = algorithmic_flops(csr_u.nnz, csr_u.shape[0], f) + algorithmic_flops(csr_i.nnz, csr_i.shape[0], f)
         res["mfma"] = mfma_view(fl / 2, (bytes_u + bytes_i) / 2, (ku + ki) / 2)
+        res["mfma"]["matrix_pipe_busy"] = {"user_sweep": pipe_busy(matrix_pipe_cycles(csr_u, f, short["users"]), ku),
+                                           "item_sweep": pipe_busy(matrix_pipe_cycles(csr_i, f, short["items"]), ki)}
     del eng, csr_u, csr_i, X, Y
     return res, shards, (Xh, Yh, wl)
 
@@ -343,6 +347,97 @@ def short_rows_note(short, csr_u, csr_i, f):
         n = int(csr.short_bounds[-1] - csr.short_bounds[nb]) if lim else 0
         out[which] = {"entry_space_form": bool(short.get(which)), "rows_within_limit": n, "rows": csr.shape[0]}
     return out
+
+
+def tile_products(n):
+    """16 x 16 tile products of a right-looking blocked Cholesky on n block rows: panel solves + trailing updates."""
+    return n * (n - 1) // 2 + (n - 1) * n * (n + 1) // 6
+
+
+def matrix_pipe_cycles(csr, f, short):
+    """Matrix-pipe cycles the exact half-sweep over `csr` issues (counted from the row lengths, not measured):
+    a bf16 MFMA (16x16x32 or 16x16x16) holds a SIMD's pipe 16 cycles, a float32 16x16x4 one 32.
+    f x f form: per 32-entry block T tiles x 6 piece products; per row the blocked Cholesky's tile products
+    (f > 64: 6 bf16 MFMAs each, else 4 float32 ones).  Entry-space form (rows of at most 16 j entries, j block rows):
+    T(j) tiles x 6 products x f/32 slices, then the j-block Cholesky.  f <= 32 (float32 accumulate) is not counted."""
+    if f <= 32:
+        return None
+    vw = 4 if f <= 64 else 8
+    T = vw * (vw + 1) // 2
+    lens = (csr.rowptr[1:] - csr.rowptr[:-1])
+    lim = 0
+    cyc = 0.0
+    if short:
+        from recommender_amd import ops
+        lim = ops.short_rows_max_entries(f)
+        ks = 2 if f <= 64 else 4
+        b = csr.short_bounds
+        for j in range(1, lim // 16 + 1):
+            rows = int((b[j - 1] if j > 1 else b[-1]) - b[j])
+            tj = j * (j + 1) // 2
+            solve = tile_products(j) * (6 * 16 if j >= 8 else 4 * 32)
+            cyc += rows * (tj * 6 * ks * 16 + solve)
+    long_rows = lens > lim
+    blocks = float(torch.div(lens[long_rows] + 31, 32, rounding_mode="floor").sum().item())
+    n_long = float(long_rows.sum().item())
+    cyc += blocks * T * 6 * 16 + n_long * tile_products(vw) * (6 * 16 if vw >= 8 else 4 * 32)
+    return cyc
+
+
+def pipe_busy(cycles_per_launch, launch_ms):
+    """Fraction of the chip's matrix-pipe time the launch's MFMAs occupy at the peak clock."""
+    if cycles_per_launch is None:
+        return None
+    return cycles_per_launch / (SIMDS * CLOCK_HZ * launch_ms * 1e-3)
+
+
+def measure_gram(dev):
+    """MFMA utilisation of the Gram (als_gram_f32) on resident factor tables: float32-equivalent flops of the
+    symmetric tiles against the float32 matrix roof (the figure of earlier rounds), and the matrix-pipe busy
+    fraction of the bf16 x 3 form it runs in for 32 < f <= 128 (T tiles x 6 products x 16 cycles per 32 rows)."""
+    from recommender_amd import ops
+    out = []
+    for n, f in [(59047, 64), (162541, 64), (59047, 128), (162541, 128), (1000000, 128)]:
+        Y = torch.randn(n, f, device=dev) * 0.1
+        gc = ops.gram(Y, 0.01)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        e0.record()
+        for _ in range(reps):
+            ops.gram(Y, 0.01, out=gc)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        vw = 4 if f <= 64 else 8
+        T = vw * (vw + 1) // 2
+        flops = n * T * 512.0
+        out.append({"rows": n, "f": f, "ms": ms, "mfma_util_f32_equivalent": flops / ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
+                    "matrix_pipe_busy": pipe_busy(n / 32.0 * T * 6 * 16, ms), "read_GBs": n * f * 4 / ms / 1e6})
+        del Y, gc
+    return out
+
+
+def measure_topk(dev, users=65536, items=1000000, f=128, k=100):
+    """The serving configuration: fused top-k of `users` users against `items` items (als_recommend_topk_f32 in blocks
+    of 4096 users), all resident.  The score GEMM runs as six bf16 piece products: its floor is 12 users items f flops
+    at the dense bf16 peak."""
+    from recommender_amd import ops
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    X = torch.randn((users, f), generator=g, device=dev) / f ** 0.5
+    Y = torch.randn((items, f), generator=g, device=dev) / f ** 0.5
+    u = torch.arange(users, device=dev)
+    ops.recommend_topk(X, Y, u[:4096], k)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ops.recommend_topk(X, Y, u, k)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    floor_ms = 12.0 * users * items * f / (MFMA_BF16_PEAK_TFLOPS * 1e12) * 1e3
+    return {"workload": "c5: fused top-%d of %d users x %d items, f=%d, blocks of 4096 users, no exclusions" % (k, users, items, f),
+            "ms": ms, "users_per_s": users / ms * 1e3, "bound": "mfma (bf16 pipe, six piece products)",
+            "floor_ms_six_bf16_products": floor_ms, "frac_of_floor": floor_ms / ms,
+            "fp32_equivalent_TFLOPs": 2.0 * users * items * f / ms / 1e9}
 
 
 def strong_scaling(workload, f, solver, world, ms_per_step):
@@ -367,6 +462,8 @@ def mfma_view(flops_per_launch, bytes_per_launch, launch_ms):
     """The same launches against the float32 matrix-core roof: above 157.3 / 8 = 19.7 flops per byte the exact
     half-sweep is bound by arithmetic, not by HBM (f = 128: 38 flops per byte on MovieLens-like rows, 58 on rows of
     about 100 entries, where the f^3 / 3 of the solve weighs as much as the accumulation)."""
+    # `frac` is float32-EQUIVALENT flops over the float32 matrix roof: the bf16 x 3 products run on a pipe 16 times
+    # faster, so it is not a utilisation - `matrix_pipe_busy` (added by the callers) is: MFMA cycles issued / pipe time
     tf = flops_per_launch / (launch_ms * 1e-3) / 1e12
     return {"bound_by": "mfma" if flops_per_launch / bytes_per_launch > MFMA_F32_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS else "hbm",
             "flops_per_byte": flops_per_launch / bytes_per_launch,
@@ -478,6 +575,8 @@ def measure_rank_share(ctx, wl_name, solver, cg_steps, accumulate, row_kernel, s
     if not cg:
         fl = algorithmic_flops(csr_u.nnz, csr_u.shape[0], f) + algorithmic_flops(csr_i.nnz, csr_i.shape[0], f)
         res["mfma"] = mfma_view(fl / 2, (bu + bi) / 2, (ku + ki) / 2)
+        res["mfma"]["matrix_pipe_busy"] = {"user_sweep": pipe_busy(matrix_pipe_cycles(csr_u, f, short["users"]), ku),
+                                           "item_sweep": pipe_busy(matrix_pipe_cycles(csr_i, f, short["items"]), ki)}
     del X, Y
     return res, state
 
@@ -594,6 +693,15 @@ def main():
             del state
             torch.cuda.empty_cache()
 
+    extra = {}
+    if not args.no_also and world == 1 and args.workload == "c2_ml25m_syn" and not args.factors:
+        for key, fn in (("gram", measure_gram), ("serving_topk", measure_topk)):
+            try:
+                extra[key] = fn(ctx.dev)
+            except Exception as exc:
+                extra[key] = {"error": repr(exc)}
+            torch.cuda.empty_cache()
+
     ranks = None
     if world > 1:
         mine = {"rank": rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name(),
@@ -630,8 +738,16 @@ def main():
         for k in ("exchange", "scaling"):
             if k in head:
                 out[k if k == "exchange" else "strong_scaling"] = head[k]
+        avg_ms = (head["launch_ms"]["user_sweep"] + head["launch_ms"]["item_sweep"]) / 2
+        out["roofline"]["achieved_kind"] = "algorithmic bytes per launch / launch time (gathers served by caches count)"
+        if traffic is not None:
+            out["roofline"]["hbm_measured_GBs"] = traffic / (avg_ms * 1e-3) / 1e9
+            out["roofline"]["hbm_measured_frac"] = traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if "mfma" in head:
+            out["roofline"]["bound"] = head["mfma"]["bound_by"]      # from the flops per byte of this workload
         if also:
             out["also"] = also
+        out.update(extra)
         if world == 1 and not args.no_cpu_baseline and Xh is not None:
             out["cpu_baseline"] = cpu_baseline(shards[0], shards[1], Xh, Yh, wl, args.cpu_seconds)
         print(json.dumps(out), flush=True)
