@@ -56,8 +56,17 @@ int32_t als_abi_version(void);
  *       ALS_ACCUMULATE_BF16X3 (default)  every value is cut exactly into three bf16 pieces and the six
  *           significant piece products run on the bf16 matrix cores, accumulated in float32; error
  *           at the level of float32 rounding (the dropped products are < 2^-23 of each term);
+ *       ALS_ACCUMULATE_FP16X2            every value, scaled by a power of two chosen per call, is cut into two fp16
+ *           pieces (22 mantissa bits) and the three significant piece products run on the fp16 matrix
+ *           cores: half the matrix work of BF16X3, error 2^-21 per term.  The scale comes from bounds:
+ *           max_rating (an upper bound of the CSR's ratings, REQUIRED for this mode: a larger rating overflows
+ *           fp16 and the row's factors become NaN) and the largest diagonal entry of Y^T Y, which als_gram_f32
+ *           leaves behind the tile-order Gram.
  *       ALS_ACCUMULATE_FP32              float32 matrix-core fma chain in CSR order (v_mfma_f32_16x16x4_f32).
- *       Both are deterministic and independent of the launch geometry.  f <= 16 always uses FP32.
+ *       ALS_ACCUMULATE_DEFAULT           FP16X2 if max_rating > 0 was given and the fixed factor has at least 16 rows
+ *           per factor (n_opp >= 16 f: with fewer the Gram is close to singular and the larger product error of
+ *           FP16X2 shows in the solution), else BF16X3.
+ *       All are deterministic and independent of the launch geometry.  f <= 16 always uses FP32.
  *       (The Gram of als_gram_f32 takes no options: bf16 x 3 for 32 < f <= 128, float32 otherwise.)
  *   row_kernel  which per-row kernel handles 64 < f <= 128 (both return the same bits):
  *       ALS_ROW_KERNEL_WAVE       one wavefront owns a row's whole matrix (144 accumulator registers);
@@ -77,6 +86,7 @@ int32_t als_abi_version(void);
 #define ALS_ACCUMULATE_DEFAULT 0
 #define ALS_ACCUMULATE_BF16X3 1
 #define ALS_ACCUMULATE_FP32 2
+#define ALS_ACCUMULATE_FP16X2 3
 #define ALS_ROW_KERNEL_AUTO 0
 #define ALS_ROW_KERNEL_WAVE 1
 #define ALS_ROW_KERNEL_STREAM 2
@@ -86,6 +96,7 @@ typedef struct {
     int32_t row_kernel;
     void *tap_begin;
     void *tap_end;
+    float max_rating;            /* an upper bound of the CSR's ratings, 0 = unknown (see accumulate)             */
     const float *whitened;       /* [device] table of als_whiten_f32 for Yopp, or NULL (see "Short rows" below)  */
     int64_t ld_whitened;         /* its leading dimension (>= 2 f, a multiple of 4)                              */
     const int64_t *short_bounds; /* [host] the ALS_SHORT_MAX_GROUPS + 2 entries of als_plan_short_bounds         */
@@ -132,7 +143,8 @@ int32_t als_plan_fill(const int64_t *rowptr_host, int64_t n_rows, int32_t chunk_
  *
  * gram_out   [device] f*f floats, row major: Y^T Y (no lambda), exactly symmetric.
  * tiles_out  [device] als_gram_tiles_bytes(f) bytes: Y^T Y + lamb*I in the register-tile
- *            order the half-sweep kernel consumes (opaque to the caller).
+ *            order the half-sweep kernel consumes, followed (f <= 128) by sqrt(max_k (Y^T Y)_kk), the bound of
+ *            |y| the fp16 x 2 accumulate takes its operand scale from (opaque to the caller).
  * The sum over rows is a fixed three-level tree (256-row chunks, 8 runs of 32 chunks per 65 536 rows, then
  * the groups in order), so a Gram assembled from als_gram_partials_f32 calls on several
  * devices equals the single-device one bit for bit.
@@ -141,13 +153,14 @@ int32_t als_plan_fill(const int64_t *rowptr_host, int64_t n_rows, int32_t chunk_
  * such f and it takes gram_out and lamb).
  * ------------------------------------------------------------------------------------ */
 size_t als_gram_tiles_bytes(int32_t f);
+size_t als_gram_partial_bytes(int32_t f);      /* bytes of one second-level partial (als_gram_partials_f32) */
 size_t als_gram_workspace_bytes(int64_t n, int32_t f);
 int32_t als_gram_f32(const float *Y, int64_t n, int32_t f, int64_t ldy, float lamb, float *gram_out,
                      float *tiles_out, void *workspace, size_t ws_bytes, void *stream);
 
 /* Second-level partials for rows [row_begin, row_end) of Y; row_begin must be a multiple
  * of ALS_GRAM_SUPER_ROWS.  Writes ceil((row_end-row_begin)/ALS_GRAM_SUPER_ROWS) partials
- * of als_gram_tiles_bytes(f) bytes each to super_out [device].  Workspace as for
+ * of als_gram_partial_bytes(f) bytes each to super_out [device].  Workspace as for
  * als_gram_workspace_bytes(row_end - row_begin, f).  (Multi-device Gram, no reference
  * counterpart: the reference is single device.) */
 int32_t als_gram_partials_f32(const float *Y, int64_t row_begin, int64_t row_end, int32_t f, int64_t ldy,

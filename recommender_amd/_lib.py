@@ -23,7 +23,7 @@ MAX_FACTORS = 256
 MAX_FACTORS_EXACT = 128
 GRAM_WIDE_CHUNK_ROWS = 4096
 SHORT_MAX_GROUPS = 8
-ACCUMULATE_MODES = {"default": 0, "bf16x3": 1, "fp32": 2}
+ACCUMULATE_MODES = {"default": 0, "bf16x3": 1, "fp32": 2, "fp16x2": 3}
 ROW_KERNELS = {"auto": 0, "wave": 1, "stream": 2}
 CG_FORMS = {"auto": 0, "lock_step": 1, "matrix": 2}
 
@@ -36,6 +36,7 @@ SIGNATURES = {
     "als_plan_count": (c_i32, [c_vp, c_i64, c_i32, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "als_plan_fill": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp]),
     "als_gram_tiles_bytes": (c_sz, [c_i32]),
+    "als_gram_partial_bytes": (c_sz, [c_i32]),
     "als_gram_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "als_gram_f32": (c_i32, [c_vp, c_i64, c_i32, c_i64, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "als_gram_partials_f32": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i64, c_vp, c_vp, c_sz, c_vp]),
@@ -69,7 +70,7 @@ SIGNATURES = {
 class SweepOpts(ctypes.Structure):
     """als_sweep_opts_t of include/als_hip.h."""
     _fields_ = [("accumulate", c_i32), ("row_kernel", c_i32), ("tap_begin", c_vp), ("tap_end", c_vp),
-                ("whitened", c_vp), ("ld_whitened", c_i64), ("short_bounds", c_vp)]
+                ("max_rating", c_f32), ("whitened", c_vp), ("ld_whitened", c_i64), ("short_bounds", c_vp)]
 
 
 class AlsHipError(RuntimeError):

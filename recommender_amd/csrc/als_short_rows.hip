@@ -27,7 +27,7 @@
 int als_fail_(int code, const char *fmt, ...);
 int32_t als_short_rows_launch_(const int32_t *col, const float *val, const int64_t *row_ids, const als_item_t *items,
                                const int64_t *bounds, int32_t nb_max, const float *WZ, int64_t ldw, int32_t f, float alpha,
-                               float *Xown, int64_t ldx, float *rowdiff, int32_t *info, hipStream_t st);
+                               float rmax_f16, float *Xown, int64_t ldx, float *rowdiff, int32_t *info, hipStream_t st);
 
 #define ALS_HIP_CHECK3(expr)                                                                          \
     do {                                                                                              \
@@ -51,6 +51,7 @@ struct ShortParams {
     int64_t ldw, ldx;
     int32_t f;
     float alpha;
+    float rmax;           // fp16 x 2 form: an upper bound of the ratings
 };
 
 // 8 consecutive factor indices of one entry's row, scaled by s, as the lane's operand fragment of each bf16 piece
@@ -68,13 +69,28 @@ __device__ __forceinline__ void split8_scaled(const f32x4 &a, const f32x4 &b, co
     }
 }
 
+// The same in the fp16 x 2 form (als_kernels.hip): two fp16 pieces of s x.
+__device__ __forceinline__ void split8_scaled_f16(const f32x4 &a, const f32x4 &b, const float s, unsigned (&H)[4],
+                                                  unsigned (&L)[4]) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float x0 = s * (p < 2 ? a[2 * p] : b[2 * p - 4]), x1 = s * (p < 2 ? a[2 * p + 1] : b[2 * p - 3]);
+        const unsigned h = pack_f16_pinned(x0, x1);
+        H[p] = h;
+        L[p] = pack_f16(x0 - f16_lo(h), x1 - f16_hi(h));
+    }
+}
+
 // waves per SIMD the kernel's register budget is sized for
 __host__ __device__ constexpr int short_waves(const int NB) { return NB <= 2 ? 4 : NB <= 4 ? 3 : NB <= 6 ? 2 : 1; }
 
 // One wave per row.  Items [first_item, first_item + gridDim.x) of p.items are whole rows with at most 16 NB entries.
 // KS = 32-wide slices of the factor index (f <= 32 KS); FULL: f == 32 KS.
 // Lane (g, i) = (lane >> 4, lane & 15) holds, of entry 16 a + i (a < NB), the factor indices 32 ks + 8 g .. + 7.
-template <int NB, int KS, bool FULL>
+// F16: the products V V^T in the fp16 x 2 form - the whitened rows have entries of magnitude at most 1
+// (W^T W = I - lamb G^-1), so the operand bound is sqrt(alpha rmax) alone.
+template <int NB, int KS, bool FULL, bool F16>
 __global__ __launch_bounds__(64, short_waves(NB)) void short_rows_kernel(const ShortParams p, const int64_t first_item) {
     using G = Geo<NB>;
     const int lane = threadIdx.x, g = lane >> 4, i = lane & 15;
@@ -105,6 +121,7 @@ __global__ __launch_bounds__(64, short_waves(NB)) void short_rows_kernel(const S
     // nothing but rows the user touched is ever read.
     uint32_t off[NB];
     float sq[NB], rhs[NB];
+    const OpScale opsc = F16 ? op_scale(__builtin_sqrtf(p.alpha * p.rmax)) : OpScale{1.f, 1.f};
     const uint32_t off_first = (uint32_t)p.col[it.begin] * ldu;
 #pragma unroll
     for (int a = 0; a < NB; ++a) {
@@ -152,23 +169,42 @@ __global__ __launch_bounds__(64, short_waves(NB)) void short_rows_kernel(const S
         if (ks + 1 < KS) load_w(ks + 1, va[(ks + 1) & 1], vb[(ks + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
         unsigned H[NB][4], M[NB][4], L[NB][4];
+        if constexpr (F16) {
 #pragma unroll
-        for (int a = 0; a < NB; ++a) split8_scaled(va[ks & 1][a], vb[ks & 1][a], sq[a], H[a], M[a], L[a]);
-        // per tile the six significant piece products, smallest first; the tiles inner, so that consecutive
-        // MFMAs go to different accumulators
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // 0: H, 1: M, 2: L
+            for (int a = 0; a < NB; ++a) split8_scaled_f16(va[ks & 1][a], vb[ks & 1][a], sq[a] * opsc.s, H[a], L[a]);
+            constexpr int FA[3] = {2, 0, 0}, FB[3] = {0, 2, 0};      // lo.hi, hi.lo, hi.hi
 #pragma unroll
-        for (int pr = 0; pr < 6; ++pr)
+            for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
-            for (int ta = 0; ta < NB; ++ta)
+                for (int ta = 0; ta < NB; ++ta)
 #pragma unroll
-                for (int tb = ta; tb < NB; ++tb) {
-                    const int t = tile_index(ta, tb, NB);
-                    const unsigned (&A)[4] = PA[pr] == 0 ? H[ta] : PA[pr] == 1 ? M[ta] : L[ta];
-                    const unsigned (&B)[4] = PB[pr] == 0 ? H[tb] : PB[pr] == 1 ? M[tb] : L[tb];
-                    T[t] = mfma_bf16(A, B, T[t]);
-                }
+                    for (int tb = ta; tb < NB; ++tb) {
+                        const int t = tile_index(ta, tb, NB);
+                        T[t] = mfma_f16(FA[pr] == 0 ? H[ta] : L[ta], FB[pr] == 0 ? H[tb] : L[tb], T[t]);
+                    }
+        } else {
+#pragma unroll
+            for (int a = 0; a < NB; ++a) split8_scaled(va[ks & 1][a], vb[ks & 1][a], sq[a], H[a], M[a], L[a]);
+            // per tile the six significant piece products, smallest first; the tiles inner, so that consecutive
+            // MFMAs go to different accumulators
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // 0: H, 1: M, 2: L
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                for (int ta = 0; ta < NB; ++ta)
+#pragma unroll
+                    for (int tb = ta; tb < NB; ++tb) {
+                        const int t = tile_index(ta, tb, NB);
+                        const unsigned (&A)[4] = PA[pr] == 0 ? H[ta] : PA[pr] == 1 ? M[ta] : L[ta];
+                        const unsigned (&B)[4] = PB[pr] == 0 ? H[tb] : PB[pr] == 1 ? M[tb] : L[tb];
+                        T[t] = mfma_bf16(A, B, T[t]);
+                    }
+        }
         __builtin_amdgcn_sched_barrier(0);      // one slice's operands at a time
+    }
+    if constexpr (F16) {
+#pragma unroll
+        for (int t = 0; t < G::NT; ++t) T[t] *= opsc.inv2;
     }
     // ---- I + V V^T, solved in place
 #pragma unroll
@@ -358,8 +394,13 @@ template <int NB, int KS>
 void launch_short(const ShortParams &p, const int64_t first, const int64_t count, hipStream_t st) {
     if (count <= 0) return;
     const dim3 grid((unsigned)count), block(64);
-    if (p.f == 32 * KS) hipLaunchKernelGGL((short_rows_kernel<NB, KS, true>), grid, block, 0, st, p, first);
-    else hipLaunchKernelGGL((short_rows_kernel<NB, KS, false>), grid, block, 0, st, p, first);
+    if (p.rmax > 0.f) {
+        if (p.f == 32 * KS) hipLaunchKernelGGL((short_rows_kernel<NB, KS, true, true>), grid, block, 0, st, p, first);
+        else hipLaunchKernelGGL((short_rows_kernel<NB, KS, false, true>), grid, block, 0, st, p, first);
+    } else {
+        if (p.f == 32 * KS) hipLaunchKernelGGL((short_rows_kernel<NB, KS, true, false>), grid, block, 0, st, p, first);
+        else hipLaunchKernelGGL((short_rows_kernel<NB, KS, false, false>), grid, block, 0, st, p, first);
+    }
 }
 
 }  // namespace
@@ -369,8 +410,9 @@ void launch_short(const ShortParams &p, const int64_t first, const int64_t count
 // items [bounds[j], bounds[j - 1]); the empty rows [bounds[0], end) go with the first group.
 int32_t als_short_rows_launch_(const int32_t *col, const float *val, const int64_t *row_ids, const als_item_t *items,
                                const int64_t *bounds, int32_t nb_max, const float *WZ, int64_t ldw, int32_t f, float alpha,
-                               float *Xown, int64_t ldx, float *rowdiff, int32_t *info, hipStream_t st) {
+                               float rmax_f16, float *Xown, int64_t ldx, float *rowdiff, int32_t *info, hipStream_t st) {
     ShortParams p;
+    p.rmax = rmax_f16;            // > 0: the fp16 x 2 form of the products with this bound of the ratings; 0: bf16 x 3
     p.col = col; p.val = val; p.row_ids = row_ids; p.items = items; p.WZ = WZ; p.X = Xown; p.rowdiff = rowdiff;
     p.info = info; p.ldw = ldw; p.ldx = ldx; p.f = f; p.alpha = alpha;
     const int64_t end = bounds[ALS_SHORT_MAX_GROUPS + 1];

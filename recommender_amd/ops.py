@@ -61,18 +61,17 @@ def _factor_ld(t, name):
 
 
 def sweep_opts(accumulate="default", row_kernel="auto", tap=None):
-    """Per-call options of the half-sweeps (als_sweep_opts_t), or None when every one is the default.
-    accumulate: "bf16x3" (= "default": the per-row normal matrix is accumulated on the bf16 matrix cores
-    from an exact 3-way split of every float32 value) or "fp32" (float32 matrix-core fma chain).
+    """Per-call options of the half-sweeps (als_sweep_opts_t).
+    accumulate: "fp16x2" (= "default" for a DeviceCSR, which knows its largest rating: operands scaled by a power of
+    two and cut into two fp16 pieces, three piece products on the fp16 matrix cores), "bf16x3" (three bf16 pieces,
+    six products) or "fp32" (float32 matrix-core fma chain).
     row_kernel: "auto", "wave" or "stream" - which per-row kernel handles 64 < f <= 128.
     tap: (begin, end) torch.cuda.Event pair recorded around the call's per-row kernels."""
     if accumulate not in _lib.ACCUMULATE_MODES:
         raise ValueError("accumulate must be one of %s" % sorted(_lib.ACCUMULATE_MODES))
     if row_kernel not in _lib.ROW_KERNELS:
         raise ValueError("row_kernel must be one of %s" % sorted(_lib.ROW_KERNELS))
-    if accumulate == "default" and row_kernel == "auto" and tap is None:
-        return None
-    o = _lib.SweepOpts(_lib.ACCUMULATE_MODES[accumulate], _lib.ROW_KERNELS[row_kernel], None, None, None, 0, None)
+    o = _lib.SweepOpts(accumulate=_lib.ACCUMULATE_MODES[accumulate], row_kernel=_lib.ROW_KERNELS[row_kernel])
     if tap is not None:
         o.tap_begin, o.tap_end = tap[0].cuda_event, tap[1].cuda_event
         o._tap = tap            # keeps the events alive, and lets a call made of several library calls record them itself
@@ -133,6 +132,7 @@ class DeviceCSR:
             raise ValueError("column index out of range [0, %d)" % n_cols)
         if val.numel() and not bool(torch.all(val >= 0)):      # also rejects NaN
             raise ValueError("ratings must be >= 0 (confidence 1 + alpha r; the kernels take sqrt(alpha r))")
+        self.max_rating = float(val.max()) if val.numel() else 0.0      # the operand bound of the fp16 x 2 accumulate
         self.shape = (n_rows, n_cols)
         self.nnz = int(col.shape[0])
         self.chunk_nnz = int(chunk_nnz)
@@ -311,7 +311,7 @@ def gram_partials(Y, row_begin, row_end, super_out=None, ws=None):
     if not (0 <= row_begin < row_end <= Y.shape[0]):
         raise ValueError("bad row range")
     n_super = -(-(row_end - row_begin) // _lib.GRAM_SUPER_ROWS)
-    elems = lib.als_gram_tiles_bytes(f) // 4
+    elems = lib.als_gram_partial_bytes(f) // 4
     if elems == 0:
         raise ValueError("unsupported factor count f=%d" % f)
     if super_out is None:
@@ -368,16 +368,18 @@ def half_sweep(csr, Yopp, gram_cache, Xown, alpha, absdiff=None, info=None, opts
         raise ValueError("Xown and Yopp must not alias")
     if absdiff is None:
         absdiff = torch.zeros(1, dtype=torch.float64, device=csr.device)
+    o = _lib.SweepOpts()
+    if opts is not None:
+        o.accumulate, o.row_kernel, o.tap_begin, o.tap_end = opts.accumulate, opts.row_kernel, opts.tap_begin, opts.tap_end
+    o.max_rating = csr.max_rating          # the bound the fp16 x 2 accumulate (the default) takes its scale from
+    o._keep = (opts,)
+    opts = o
     if short_rows:
         wz = gram_cache.whitened
         if wz is None or wz.shape[0] < csr.shape[1] or wz.shape[1] != 2 * f or wz.device != csr.device:
             raise ValueError("short_rows=True needs gram_cache.whitened for this factor (ops.whiten)")
-        o = _lib.SweepOpts(0, 0, None, None, None, 0, None)
-        if opts is not None:
-            o.accumulate, o.row_kernel, o.tap_begin, o.tap_end = opts.accumulate, opts.row_kernel, opts.tap_begin, opts.tap_end
         o.whitened, o.ld_whitened, o.short_bounds = wz.data_ptr(), wz.stride(0), csr.short_bounds.ctypes.data
-        o._keep = (opts, wz, csr.short_bounds)
-        opts = o
+        o._keep = (o._keep, wz, csr.short_bounds)
     if static_scratch:
         with torch.cuda.device(csr.device):
             check(lib.als_half_sweep_csr_static_f32(
@@ -439,7 +441,7 @@ def half_sweep_cg(csr, Yopp, gram_cache, Xown, alpha, cg_steps, absdiff=None, in
         parts = torch.zeros(len(slabs), dtype=torch.float64, device=csr.device)
         tap = getattr(opts, "_tap", None) if opts is not None else None
         if tap is not None:         # the tap brackets all slabs, not the last one
-            opts = _lib.SweepOpts(opts.accumulate, opts.row_kernel, None, None, None, 0, None)
+            opts = _lib.SweepOpts(accumulate=opts.accumulate, row_kernel=opts.row_kernel, max_rating=opts.max_rating)
             with torch.cuda.device(csr.device):
                 tap[0].record(torch.cuda.current_stream())
         for k, (r0, r1, sub) in enumerate(slabs):
@@ -451,6 +453,12 @@ def half_sweep_cg(csr, Yopp, gram_cache, Xown, alpha, cg_steps, absdiff=None, in
                 tap[1].record(torch.cuda.current_stream())
         torch.sum(parts, 0, keepdim=True, out=absdiff)           # slab order: a fixed order
         return absdiff
+    o = _lib.SweepOpts()
+    if opts is not None:
+        o.accumulate, o.row_kernel, o.tap_begin, o.tap_end = opts.accumulate, opts.row_kernel, opts.tap_begin, opts.tap_end
+    o.max_rating = csr.max_rating          # the formed-matrix form accumulates as the exact half-sweep does
+    o._keep = (opts,)
+    opts = o
     ws = csr.workspace_cg(f) if _ws is None else _ws
     if ws.numel() < lib.als_half_sweep_cg_workspace_bytes(csr.shape[0], csr.n_slots, f):
         raise ValueError("shared workspace too small for this slab")

@@ -207,9 +207,11 @@ def test_invalid_arguments_raise(ra):
 
 @pytest.mark.parametrize("f", [20, 64, 100, 128])
 def test_accumulate_modes_agree_and_both_hold_parity(ra, f):
-    """The bf16 x 3 accumulate (default) and the float32 fma-chain accumulate are two roundings of
-    the same sums: both within 1e-4 of the float64 oracle, within 2e-5 of each other, and each
-    bit-for-bit reproducible.  Long rows (chunk_nnz = 128) and ragged 32-entry blocks included."""
+    """The fp16 x 2 accumulate (the default when the CSR's largest rating is known and the fixed factor has at least 16
+    rows per factor), the bf16 x 3 accumulate and the float32 fma-chain accumulate are three roundings of the same
+    sums: each within 1e-4 of the float64 oracle, within 2e-5 of each other, and each bit-for-bit reproducible.  Long
+    rows (chunk_nnz = 128) and ragged 32-entry blocks included.  A deliberately loose rating bound (1000 times the
+    largest rating: 5 of fp16's bits given away) must not cost the bar either."""
     rng = np.random.default_rng(300 + f)
     N, M = 1200, 2500
     ptr, ind, dat = _random_csr(rng, N, M, 45, 2400)
@@ -217,16 +219,24 @@ def test_accumulate_modes_agree_and_both_hold_parity(ra, f):
     X0 = rng.normal(0, 1 / np.sqrt(f), size=(N, f)).astype(np.float32)
     ref = c_oracle.half_sweep(ptr, ind, dat, Y0, X0, 0.01, 40.0, dtype=np.float64, nthreads=8)
     out = {}
-    for mode in ("fp32", "bf16x3"):       # a per-call option: nothing to restore afterwards
+    for mode in ("fp32", "bf16x3", "fp16x2"):       # a per-call option: nothing to restore afterwards
         o = ra.ops.sweep_opts(accumulate=mode)
         a, _ = _sweep(ra, ptr, ind, dat, (N, M), Y0, X0, 0.01, 40.0, chunk_nnz=128, opts=o)
         b, _ = _sweep(ra, ptr, ind, dat, (N, M), Y0, X0, 0.01, 40.0, chunk_nnz=128, opts=o)
         assert np.array_equal(a, b)
         assert _rel(a, ref) < 1e-4, (mode, _rel(a, ref))
         out[mode] = a
-    assert _rel(out["bf16x3"], out["fp32"]) < 2e-5
+    assert _rel(out["bf16x3"], out["fp32"]) < 2e-5 and _rel(out["fp16x2"], out["fp32"]) < 2e-5
     dflt, _ = _sweep(ra, ptr, ind, dat, (N, M), Y0, X0, 0.01, 40.0, chunk_nnz=128)
-    assert np.array_equal(dflt, out["bf16x3"])          # no options = the documented default
+    # no options = the documented default: fp16 x 2 where the kernels have a split form (f > 16) and M >= 16 f
+    assert np.array_equal(dflt, out["fp16x2" if M >= 16 * f else "bf16x3"])
+    if f > 16:
+        csr = ra.DeviceCSR(ptr, ind, dat, (N, M), "cuda", chunk_nnz=128)
+        csr.max_rating *= 1000.0
+        Y = _dev(Y0); X = _dev(X0)
+        ra.half_sweep(csr, Y, ra.gram(Y, 0.01), X, 40.0, opts=ra.ops.sweep_opts(accumulate="fp16x2"))
+        torch.cuda.synchronize()
+        assert _rel(X.cpu().numpy().astype(np.float64), ref) < 1e-4
 
 
 def test_integration_stub_from_the_docs_runs(ra):

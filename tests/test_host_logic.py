@@ -31,7 +31,7 @@ def test_error_strings_and_argument_checks_without_gpu():
     assert rc == 1 and b"non-decreasing" in lib.als_last_error_string()
     rc = lib.als_plan_count(ptr.ctypes.data, 2, 100, ctypes.byref(n), ctypes.byref(n), ctypes.byref(n))
     assert rc == 1 and b"multiple of 64" in lib.als_last_error_string()
-    assert lib.als_gram_tiles_bytes(0) == 0 and lib.als_gram_tiles_bytes(64) == 40 * 64 * 4
+    assert lib.als_gram_tiles_bytes(0) == 0 and lib.als_gram_tiles_bytes(64) == 40 * 64 * 4 + 256 and lib.als_gram_partial_bytes(64) == 40 * 64 * 4
     assert lib.als_half_sweep_workspace_bytes(10, 0, 1000) == 0
 
 
