@@ -58,8 +58,9 @@ def parse():
     ap.add_argument("--cg-form", default="auto", choices=["auto", "matrix", "lock_step"],
                     help="cg: on the formed matrix (one gather pass) or all rows in lock step (cg_steps+1 passes); "
                          "auto = matrix for f <= 128, lock_step above")
-    ap.add_argument("--accumulate", default="bf16x3", choices=["bf16x3", "fp32"],
-                    help="exact solver: how the per-row normal matrix is accumulated (see include/als_hip.h)")
+    ap.add_argument("--accumulate", default="default", choices=["default", "fp16x2", "bf16x3", "fp32"],
+                    help="exact solver: how the per-row normal matrix is accumulated (see include/als_hip.h; default = the "
+                         "library's choice: fp16x2 where the fixed factor has at least 16 rows per factor, else bf16x3)")
     ap.add_argument("--row-kernel", default="auto", choices=["auto", "wave", "stream"],
                     help="64 < f <= 128: one wavefront per row, or one resident wavefront per SIMD streaming its rows")
     ap.add_argument("--short-rows", default="auto", choices=["auto", "on", "off"],
@@ -309,14 +310,14 @@ def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel,
         "workload": "%s: %d users x %d items, %d nnz, f=%d, lamb=%g, alpha=%g, %s"
                     % (workload, N, M, nnz, f, wl["lamb"], wl["alpha"],
                        "%d conjugate-gradient steps per row (%s)" % (cg_steps, "lock step" if lockstep else "formed matrix")
-                       if cg else "exact Cholesky solve, %s accumulate" % accumulate),
+                       if cg else "exact Cholesky solve, %s accumulate" % ("fp16x2" if accumulate == "default" else accumulate)),
         "nnz": nnz, "f": f, "solver": solver, "cg_steps": cg_steps if cg else None, "steps": steps, "seconds": dt,
         "value": 2.0 * nnz * steps / dt, "ms_per_step": dt / steps * 1e3,
         "kernel": ("cg half-sweep (cg_items_kernel passes + Gram GEMM)" if lockstep else
                    "per-row kernels of the half-sweep (%s: gather/accumulate + %s; the long rows' combine and solve "
                    "included)" % ("wide_row_items_kernel" if f > 128 else
                                   "sweep_stream_kernel for whole rows (row_kernel=%s), sweep_items_kernel for long rows' chunks"
-                                  % row_kernel if f > 64 and row_kernel != "wave" and accumulate == "bf16x3" else
+                                  % row_kernel if f > 64 and row_kernel != "wave" and accumulate != "fp32" else
                                   "sweep_items_kernel, row_kernel=%s" % row_kernel,
                                   "CG on the formed matrix" if cg else "solve")),
         "achieved": achieved, "launch_ms": {"user_sweep": ku, "item_sweep": ki},
@@ -331,8 +332,8 @@ def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel,
     if not cg:
         fl = algorithmic_flops(csr_u.nnz, csr_u.shape[0], f) + algorithmic_flops(csr_i.nnz, csr_i.shape[0], f)
         res["mfma"] = mfma_view(fl / 2, (bytes_u + bytes_i) / 2, (ku + ki) / 2)
-        res["mfma"]["matrix_pipe_busy"] = {"user_sweep": pipe_busy(matrix_pipe_cycles(csr_u, f, short["users"]), ku),
-                                           "item_sweep": pipe_busy(matrix_pipe_cycles(csr_i, f, short["items"]), ki)}
+        res["mfma"]["matrix_pipe_busy"] = {"user_sweep": pipe_busy(matrix_pipe_cycles(csr_u, f, short["users"], accumulate), ku),
+                                           "item_sweep": pipe_busy(matrix_pipe_cycles(csr_i, f, short["items"], accumulate), ki)}
     del eng, csr_u, csr_i, X, Y
     return res, shards, (Xh, Yh, wl)
 
@@ -354,14 +355,17 @@ def tile_products(n):
     return n * (n - 1) // 2 + (n - 1) * n * (n + 1) // 6
 
 
-def matrix_pipe_cycles(csr, f, short):
+def matrix_pipe_cycles(csr, f, short, accumulate="default"):
     """Matrix-pipe cycles the exact half-sweep over `csr` issues (counted from the row lengths, not measured):
     a bf16 MFMA (16x16x32 or 16x16x16) holds a SIMD's pipe 16 cycles, a float32 16x16x4 one 32.
-    f x f form: per 32-entry block T tiles x 6 piece products; per row the blocked Cholesky's tile products
+    f x f form: per 32-entry block T tiles x 3 (fp16 x 2) or 6 (bf16 x 3) piece products; per row the blocked Cholesky's tile products
     (f > 64: 6 bf16 MFMAs each, else 4 float32 ones).  Entry-space form (rows of at most 16 j entries, j block rows):
     T(j) tiles x 6 products x f/32 slices, then the j-block Cholesky.  f <= 32 (float32 accumulate) is not counted."""
-    if f <= 32:
+    if f <= 32 or accumulate == "fp32":
         return None
+    # piece products per tile and 32 entries: three (fp16 x 2: the default where the fixed factor has at least 16 rows
+    # per factor) or six (bf16 x 3)
+    pp = 3 if accumulate == "fp16x2" or (accumulate == "default" and csr.shape[1] >= 16 * f and csr.max_rating > 0) else 6
     vw = 4 if f <= 64 else 8
     T = vw * (vw + 1) // 2
     lens = (csr.rowptr[1:] - csr.rowptr[:-1])
@@ -376,11 +380,11 @@ def matrix_pipe_cycles(csr, f, short):
             rows = int((b[j - 1] if j > 1 else b[-1]) - b[j])
             tj = j * (j + 1) // 2
             solve = tile_products(j) * (6 * 16 if j >= 8 else 4 * 32)
-            cyc += rows * (tj * 6 * ks * 16 + solve)
+            cyc += rows * (tj * pp * ks * 16 + solve)
     long_rows = lens > lim
     blocks = float(torch.div(lens[long_rows] + 31, 32, rounding_mode="floor").sum().item())
     n_long = float(long_rows.sum().item())
-    cyc += blocks * T * 6 * 16 + n_long * tile_products(vw) * (6 * 16 if vw >= 8 else 4 * 32)
+    cyc += blocks * T * pp * 16 + n_long * tile_products(vw) * (6 * 16 if vw >= 8 else 4 * 32)
     return cyc
 
 
@@ -561,7 +565,7 @@ def measure_rank_share(ctx, wl_name, solver, cg_steps, accumulate, row_kernel, s
                        "half-sweep %d x %d (%d nnz); %s; exchanges not included"
                        % (wl_name, N, M, W, f, nb, M, csr_u.nnz, mi, N, csr_i.nnz,
                           "%d conjugate-gradient steps per row (formed matrix)" % cg_steps if cg else
-                          "exact Cholesky solve, %s accumulate" % accumulate),
+                          "exact Cholesky solve, %s accumulate" % ("fp16x2" if accumulate == "default" else accumulate)),
            "f": f, "solver": solver, "cg_steps": cg_steps if cg else None, "steps": steps,
            "nnz_per_s": (csr_u.nnz + csr_i.nnz) * steps / dt, "ms_per_step": dt / steps * 1e3,
            "launch_ms": {"user_sweep": ku, "item_sweep": ki},
@@ -575,8 +579,8 @@ def measure_rank_share(ctx, wl_name, solver, cg_steps, accumulate, row_kernel, s
     if not cg:
         fl = algorithmic_flops(csr_u.nnz, csr_u.shape[0], f) + algorithmic_flops(csr_i.nnz, csr_i.shape[0], f)
         res["mfma"] = mfma_view(fl / 2, (bu + bi) / 2, (ku + ki) / 2)
-        res["mfma"]["matrix_pipe_busy"] = {"user_sweep": pipe_busy(matrix_pipe_cycles(csr_u, f, short["users"]), ku),
-                                           "item_sweep": pipe_busy(matrix_pipe_cycles(csr_i, f, short["items"]), ki)}
+        res["mfma"]["matrix_pipe_busy"] = {"user_sweep": pipe_busy(matrix_pipe_cycles(csr_u, f, short["users"], accumulate), ku),
+                                           "item_sweep": pipe_busy(matrix_pipe_cycles(csr_i, f, short["items"], accumulate), ki)}
     del X, Y
     return res, state
 
