@@ -8,7 +8,7 @@ out = sys.argv[1]
 
 def short(name):
     n = name
-    for k in ("sweep_stream_kernel", "scores_split_kernel", "topk_rows_kernel", "select_candidates_kernel", "wide_row_items_kernel",
+    for k in ("sweep_stream_kernel", "short_rows_kernel", "whiten_factor_kernel", "gram_bound_kernel", "scores_split_kernel", "topk_rows_kernel", "select_candidates_kernel", "wide_row_items_kernel",
               "sweep_items_kernel", "sweep_long_rows_kernel", "gram_chunk_kernel", "gram_finalize_kernel",
               "sum_groups_kernel", "sum_to_double_kernel", "cg_items_kernel", "cg_long_rows_kernel", "scores_kernel",
               "gram_wide_chunk_kernel", "sum_slots_kernel"):
@@ -50,7 +50,7 @@ for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
 # LDS-DMA alike - the sweep's gathers) at 64 bytes, so the read side is doubled; WRITE_SIZE is exact.  Infinity-Cache
 # hits are counted in, not excluded.
 import json
-ROW_KERNELS = ("sweep_stream_kernel", "sweep_items_kernel", "sweep_long_rows_kernel", "sum_slots_kernel", "wide_row_items_kernel",
+ROW_KERNELS = ("sweep_stream_kernel", "short_rows_kernel", "sweep_items_kernel", "sweep_long_rows_kernel", "sum_slots_kernel", "wide_row_items_kernel",
                "cg_items_kernel", "cg_long_rows_kernel")
 fetch, write = {}, {}
 for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
