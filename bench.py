@@ -720,7 +720,7 @@ def main():
             "metric": "ALS nnz/sec (2*nnz per iteration; iterations/sec in iters_per_s)",
             "value": head["value"], "unit": "nnz/s", "iters_per_s": args.steps / head["seconds"],
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if "scaling" in head else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": head["workload"],
                        "parallelism": "dp%d (user/item row shards, all-gather of factors)" % world},
             "roofline": {"bound": "hbm", "kernel": head["kernel"],

@@ -53,7 +53,7 @@ int32_t als_abi_version(void);
  * every default; nothing here is kept after the call returns and the library holds no settings
  * of its own, so concurrent callers do not affect each other.
  *   accumulate  how  sum_j alpha r_uj y_j y_j^T  is formed for 16 < f <= 128:
- *       ALS_ACCUMULATE_BF16X3 (default)  every value is cut exactly into three bf16 pieces and the six
+ *       ALS_ACCUMULATE_BF16X3            every value is cut exactly into three bf16 pieces and the six
  *           significant piece products run on the bf16 matrix cores, accumulated in float32; error
  *           at the level of float32 rounding (the dropped products are < 2^-23 of each term);
  *       ALS_ACCUMULATE_FP16X2            every value, scaled by a power of two chosen per call, is cut into two fp16

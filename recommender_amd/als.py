@@ -265,6 +265,7 @@ class ALSEngine:
         # short_rows: "auto" (short_rows_pay on the matrix's totals), True or False - whether the user / item
         # half-sweep solves rows with fewer entries than factors in their entry-space form (exact solver only)
         self.short = self._decide_short_rows(short_rows)
+        self._share_rating_bound()
         self.sweep_opts = None         # callable("users" | "items") -> ops.sweep_opts(...) for that launch, or None
         self.cache_Y = backend.GramCache(self.f, lamb, X.device)
         self.cache_X = backend.GramCache(self.f, lamb, X.device)
@@ -304,6 +305,21 @@ class ALSEngine:
             mine = [int(v) for v in t.cpu().tolist()]
         return {"users": short_rows_pay(mine[0], self.n_users, self.Y.shape[0], self.f),
                 "items": short_rows_pay(mine[1], self.n_items, self.X.shape[0], self.f)}
+
+    def _share_rating_bound(self):
+        """The fp16 x 2 accumulate scales its operands by a power of two taken from an upper bound of the ratings.  Both
+        CSRs of every rank get the largest rating of the WHOLE matrix, so that the scale - and with it every bit of
+        the factors - does not depend on how the rows were cut into shards."""
+        csrs = [c for c in (self.csr_users, self.csr_items) if hasattr(c, "max_rating")]
+        if not csrs:
+            return
+        m = max(c.max_rating for c in csrs)
+        if self.world > 1:
+            t = torch.tensor([m], dtype=torch.float64, device="cpu" if _host_staged(self.X, self.group) else self.X.device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=self.group)
+            m = float(t.cpu()[0])
+        for c in csrs:
+            c.max_rating = m
 
     def _parts(self):
         """[(row0, row1, csr chunk or None if empty, |delta| buffer)], chunk c of this rank's user shard."""

@@ -176,8 +176,10 @@ class DeviceCSR:
         ptr = self.rowptr[r0:r1 + 1]
         lo, hi = int(ptr[0]), int(ptr[-1])
         ids = None if self.row_ids is None else self.row_ids[r0:r1].cpu().numpy()
-        return DeviceCSR(ptr - lo, self.col[lo:hi], self.val[lo:hi], (r1 - r0, self.shape[1]), self.device,
-                         self.chunk_nnz, ids)
+        sub = DeviceCSR(ptr - lo, self.col[lo:hi], self.val[lo:hi], (r1 - r0, self.shape[1]), self.device,
+                        self.chunk_nnz, ids)
+        sub.max_rating = self.max_rating        # the whole matrix's bound: any cut of the rows accumulates at one scale
+        return sub
 
     def transpose(self):
         """The CSR of the transposed matrix (canonical: sorted columns), built on the device with

@@ -183,6 +183,26 @@ def test_row_shards_equal_whole(ra):
     assert np.array_equal(np.vstack([a, b]), whole)
 
 
+def test_row_chunks_with_smaller_ratings_accumulate_at_the_whole_matrix_scale(ra):
+    """The fp16 x 2 accumulate takes its operand scale from a bound of the ratings.  A chunk of rows whose own largest
+    rating is far below the matrix's (here 0.5 against 900) must still use the matrix's bound - row_range hands it down -
+    so that the chunk's rows come out bit-identical to the same rows of one call."""
+    rng = np.random.default_rng(17)
+    N, M, f = 1500, 4000, 64
+    ptr, ind, dat = _random_csr(rng, N, M, 30, 2900)
+    cut = 700
+    dat = dat.copy(); dat[: ptr[cut]] = 0.5; dat[ptr[cut]:] = rng.choice([1.0, 30.0, 900.0], size=int(ptr[-1] - ptr[cut]))
+    Y = _dev(rng.normal(0, 0.2, size=(M, f))); X0 = rng.normal(0, 0.2, size=(N, f)).astype(np.float32)
+    csr = ra.DeviceCSR(ptr, ind, dat, (N, M), "cuda")
+    assert csr.max_rating == 900.0 and csr.row_range(0, cut).max_rating == 900.0
+    gc = ra.gram(Y, 0.01)
+    whole = _dev(X0); ra.half_sweep(csr, Y, gc, whole, 0.1)
+    parts = _dev(X0)
+    ra.half_sweep(csr.row_range(0, cut), Y, gc, parts[:cut], 0.1)
+    ra.half_sweep(csr.row_range(cut, N), Y, gc, parts[cut:], 0.1)
+    assert torch.equal(parts, whole)
+
+
 def test_invalid_arguments_raise(ra):
     rng = np.random.default_rng(1)
     ptr = np.array([0, 2, 3], dtype=np.int64); ind = np.array([0, 1, 5], dtype=np.int32)

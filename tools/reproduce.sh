@@ -17,25 +17,31 @@ print("%-22s %8.2f ms/iter  %.3g nnz/s  %5.0f GB/s algorithmic (%.2f of HBM peak
 PY
 }
 run c2_f64_exact                                   && \
+run c2_f64_exact_bf16x3  --accumulate bf16x3       && \
 run c2_f64_exact_fp32    --accumulate fp32         && \
-run c2_f64_cg10          --solver cg               && \
+run c2_f64_cgdef         --solver cg               && \
 run c2_f64_cg3           --solver cg --cg-steps 3  && \
 run c2_f128_exact        --factors 128 --steps 5   && \
+run c2_f128_exact_bf16x3 --factors 128 --steps 5 --accumulate bf16x3 && \
 run c2_f128_exact_fp32   --factors 128 --steps 5 --accumulate fp32 && \
 run c2_f128_exact_wave   --factors 128 --steps 5 --row-kernel wave && \
-run c2_f128_cg10         --factors 128 --steps 5 --solver cg && \
+run c2_f128_cgdef        --factors 128 --steps 5 --solver cg && \
 run c2_f128_cg3          --factors 128 --steps 5 --solver cg --cg-steps 3 && \
 run c2_f128_cg3_lockstep --factors 128 --steps 5 --solver cg --cg-steps 3 --cg-form lock_step && \
-run c2_f256_cg10         --factors 256 --steps 5 --solver cg && \
+run c2_f256_cgdef        --factors 256 --steps 3 --solver cg && \
 run c2_f256_cg3          --factors 256 --steps 5 --solver cg --cg-steps 3 && \
 run c3shard_exact        --workload c3_shard_syn --steps 3 --warmup 1 && \
-run c3shard_exact_wave   --workload c3_shard_syn --steps 3 --warmup 1 --row-kernel wave && \
-run c3shard_cg10         --workload c3_shard_syn --steps 3 --warmup 1 --solver cg && \
+run c3shard_exact_bf16x3 --workload c3_shard_syn --steps 3 --warmup 1 --accumulate bf16x3 && \
+run c3shard_exact_noshort --workload c3_shard_syn --steps 3 --warmup 1 --short-rows off && \
+run c3shard_exact_bf16x3_noshort --workload c3_shard_syn --steps 3 --warmup 1 --accumulate bf16x3 --short-rows off && \
+run c3shard_cgdef        --workload c3_shard_syn --steps 3 --warmup 1 --solver cg && \
 run c3shard_cg3          --workload c3_shard_syn --steps 3 --warmup 1 --solver cg --cg-steps 3 && \
-run c3shard_cg3_wave     --workload c3_shard_syn --steps 3 --warmup 1 --solver cg --cg-steps 3 --row-kernel wave && \
 run c3rank_exact         --workload c3_rank_syn --steps 3 --warmup 1 && \
-run c3rank_cg10          --workload c3_rank_syn --steps 3 --warmup 1 --solver cg && \
-run c4shard_cg10         --workload c4_shard_syn --steps 2 --warmup 1 && \
+run c3rank_exact_bf16x3  --workload c3_rank_syn --steps 3 --warmup 1 --accumulate bf16x3 && \
+run c3rank_exact_noshort --workload c3_rank_syn --steps 3 --warmup 1 --short-rows off && \
+run c3rank_cgdef         --workload c3_rank_syn --steps 3 --warmup 1 --solver cg && \
+run c3full_exact         --workload c3_full_syn --steps 2 --warmup 1 && \
+run c4shard_cgdef        --workload c4_shard_syn --steps 2 --warmup 1 && \
 run c4shard_cg3          --workload c4_shard_syn --steps 2 --warmup 1 --cg-steps 3 && \
 python3 "$ROOT/tools/bench_topk.py" --users 65536 --skip-materialised && \
 python3 "$ROOT/tools/bench_topk.py" --users 1048576 --filter-rated --skip-materialised && python3 "$ROOT/tools/bench_gram.py"
