@@ -291,3 +291,28 @@ def test_integration_stub_from_the_docs_runs(ra):
     ref = c_oracle.half_sweep(ptr, ind, dat, Y0, X0, lamb, alpha, dtype=np.float64, nthreads=4)
     assert _rel(X.cpu().numpy().astype(np.float64), ref) < 1e-4
     assert float(mean_change.item()) == pytest.approx(np.abs(X0.astype(np.float64) - ref).mean(), rel=1e-4)
+
+    # the same binding with short rows in their entry-space form (f = 128) and the rating bound
+    N, M, f = 600, 4000, 128
+    ptr, ind, dat = _random_csr(rng, N, M, 40, 2500)
+    Y0 = rng.normal(0, 1 / np.sqrt(f), size=(M, f)).astype(np.float32)
+    X0 = rng.normal(0, 1 / np.sqrt(f), size=(N, f)).astype(np.float32)
+    hp = np.ascontiguousarray(ptr, dtype=np.int64)
+    plan = ns["make_plan"](hp)
+    bounds = ns["make_short_bounds"](hp)
+    Y, X = _dev(Y0), _dev(X0)
+    gram = torch.empty((f, f), device="cuda")
+    tiles = torch.empty(lib.als_gram_tiles_bytes(f), dtype=torch.uint8, device="cuda")
+    ws = torch.empty(max(lib.als_gram_workspace_bytes(M, f), 256), dtype=torch.uint8, device="cuda")
+    ns["update_cache"](Y, lamb, gram, tiles, ws)
+    WZ = torch.empty((M, 2 * f), device="cuda")
+    wws = torch.empty(lib.als_whiten_workspace_bytes(f), dtype=torch.uint8, device="cuda")
+    ns["whiten"](Y, lamb, gram, WZ, wws)
+    val = _dev(dat)
+    opts = ns["short_row_opts"](val, WZ, bounds)
+    ws2 = torch.empty(max(lib.als_half_sweep_workspace_bytes(N, plan[3], f), 256), dtype=torch.uint8, device="cuda")
+    absdiff.zero_()
+    ns["run_epoch"](_dev(ptr, torch.int64), _dev(ind, torch.int32), val, plan, Y, tiles, X, alpha, absdiff, ws2, opts)
+    torch.cuda.synchronize()
+    ref = c_oracle.half_sweep(ptr, ind, dat, Y0, X0, lamb, alpha, dtype=np.float64, nthreads=4)
+    assert _rel(X.cpu().numpy().astype(np.float64), ref) < 1e-4
