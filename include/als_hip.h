@@ -349,6 +349,30 @@ int32_t als_recommend_topk_f32(const float *X, int64_t ldx, const int64_t *user_
                                int64_t ldy, int64_t M, int32_t f, int32_t k, const int64_t *ex_rowptr,
                                const int32_t *ex_col, int32_t ex_by_user_id, int32_t *idx_out, float *score_out,
                                int32_t *overflow_out, void *workspace, size_t ws_bytes, void *stream);
+/* Prepared item tables - serving ranks many blocks of users against ONE fixed item factor (the trained Y that
+ * SimpleMFRecAlgo.recommend multiplies every request against, RecAlgos.py:20-32).  als_items_prepare_f32 converts the
+ * first M rows of Y once into the operand form of the fp16 matrix cores: every value scaled by one power of two
+ * (taken from the largest finite |y|) and cut into two fp16 pieces (22 mantissa bits for every value within 2^18 of the
+ * largest), stored in the order the score kernel's lanes read them.  The table has als_items_prepared_bytes(M, f)
+ * bytes (the size of the float32 factor, padded to 32 items, + 256), is opaque, belongs to the library version that
+ * wrote it, and must be rebuilt when Y changes.  f <= 128, f % 4 == 0, 16-byte aligned rows (als_items_prepared_bytes
+ * returns 0 for an unsupported f); the item factors must be finite.
+ * als_scores_prepared_f32 / als_recommend_topk_prepared_f32 are als_scores_f32 / als_recommend_topk_f32 against such
+ * a table (M_table: the M it was built with; M <= M_table: the items scored): user rows are scaled per row and cut the
+ * same way, three piece products per block are accumulated in float32, the scaling is undone exactly.  A score
+ * depends on its user row, its item row and the table's scale only; error <= ~2^-21 sum |x_k y_k| (als_scores_f32:
+ * 2^-23).  The two calls agree with each other bit for bit, as als_scores_f32 and als_recommend_topk_f32 do; the
+ * two-call path for users marked by overflow_out is als_scores_prepared_f32 + als_topk_rows_f32.
+ * Workspace of the top-k call: als_recommend_topk_workspace_bytes(nu, M, k). */
+size_t als_items_prepared_bytes(int64_t M, int32_t f);
+int32_t als_items_prepare_f32(const float *Y, int64_t ldy, int64_t M, int32_t f, void *prepared, size_t bytes,
+                              void *stream);
+int32_t als_scores_prepared_f32(const float *X, int64_t ldx, const int64_t *user_ids, int64_t nu, const void *prepared,
+                                int64_t M_table, int64_t M, int32_t f, float *scores, int64_t lds, void *stream);
+int32_t als_recommend_topk_prepared_f32(const float *X, int64_t ldx, const int64_t *user_ids, int64_t nu,
+                                        const void *prepared, int64_t M, int32_t f, int32_t k, const int64_t *ex_rowptr,
+                                        const int32_t *ex_col, int32_t ex_by_user_id, int32_t *idx_out, float *score_out,
+                                        int32_t *overflow_out, void *workspace, size_t ws_bytes, void *stream);
 int32_t als_predict_pairs_f32(const float *X, int64_t ldx, const float *Y, int64_t ldy, const int64_t *u,
                               const int64_t *i, int64_t n, int32_t f, float *out, void *stream);
 int32_t als_normalize_rows_f32(const float *E, int64_t lde, int64_t n, int32_t f, float *out, int64_t ldo,

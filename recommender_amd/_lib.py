@@ -44,6 +44,11 @@ SIGNATURES = {
     "als_scores_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_vp]),
     "als_topk_rows_f32": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "als_recommend_topk_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32]),
+    "als_items_prepared_bytes": (c_sz, [c_i64, c_i32]),
+    "als_items_prepare_f32": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_sz, c_vp]),
+    "als_scores_prepared_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_vp]),
+    "als_recommend_topk_prepared_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp,
+                                                c_vp, c_vp, c_vp, c_sz, c_vp]),
     "als_recommend_topk_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp,
                                        c_vp, c_vp, c_vp, c_sz, c_vp]),
     "als_predict_pairs_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),

@@ -213,6 +213,9 @@ __device__ __forceinline__ void score_dma16(const void *g, const unsigned lds) {
 }
 #pragma clang diagnostic pop
 
+#include "als_fp16.inc"
+#include "als_scores_prepared.inc"
+
 constexpr int SB_USERS = 128;   // users per workgroup
 constexpr int SB_ITEMS = 32;    // items per stage
 
@@ -439,6 +442,7 @@ __device__ __forceinline__ float key_to_float(const uint32_t k) {
 }
 
 constexpr int TOPK_MAX = 1024;
+constexpr int TOPK_REG_ITEMS = 16384;
 
 __global__ __launch_bounds__(256) void topk_rows_kernel(float *__restrict__ S, const int64_t lds, const int64_t M,
                                                        const int64_t *__restrict__ ex_rowptr,
@@ -453,6 +457,7 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(float *__restrict__ S, c
     __shared__ uint32_t wave_gt[4], wave_eq[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float *row = S + (int64_t)blockIdx.x * lds;
+    auto key_at = [&](const int64_t i) { return order_key(row[i]); };
 
     // 0. excluded items (e.g. already rated, RecommenderService.py:16-29) drop to -inf
     if (ex_rowptr) {
@@ -472,7 +477,7 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(float *__restrict__ S, c
         hist[tid] = 0;
         __syncthreads();
         for (int64_t i = tid; i < M; i += 256) {
-            const uint32_t key = order_key(row[i]);
+            const uint32_t key = key_at(i);
             if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 0xff], 1u);
         }
         __syncthreads();
@@ -499,7 +504,7 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(float *__restrict__ S, c
     const int64_t s0 = min(M, seg * wave), s1 = min(M, s0 + seg);
     uint32_t cgt = 0, ceq = 0;
     for (int64_t i = s0 + lane; i < s1; i += 64) {
-        const uint32_t key = order_key(row[i]);
+        const uint32_t key = key_at(i);
         cgt += key > T;
         ceq += key == T;
     }
@@ -520,7 +525,7 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(float *__restrict__ S, c
     }
     for (int64_t base = s0; base < s1; base += 64) {
         const int64_t i = base + lane;
-        const uint32_t key = i < s1 ? order_key(row[i]) : 0u;
+        const uint32_t key = i < s1 ? key_at(i) : 0u;
         const bool gt = i < s1 && key > T, eq = i < s1 && key == T;
         const unsigned long long bg = __ballot(gt), be = __ballot(eq);
         const unsigned long long below = (1ull << lane) - 1ull;
@@ -570,16 +575,160 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(float *__restrict__ S, c
     }
 }
 
+// The same selection for rows of at most TOPK_REG_ITEMS scores (the first range of the fused top-k): a thread keeps its
+// 64 keys (items q 256 + tid) in registers and the row is read once.  The k-th largest key is found bit by bit - T takes
+// bit b if at least k keys are >= T | 1 << b: 32 counting rounds over registers, no histogram, no atomics (on scores of
+// one magnitude the top-byte histogram of the kernel above funnels the whole row through a handful of LDS counters).
+// Then the keys above T and the first `remaining` equal to it, in item order: per (q, wave) segment the counts go
+// through LDS, one scan gives every segment its offset.  Same sort, same output as topk_rows_kernel.
+__global__ __launch_bounds__(256) void topk_rows_reg_kernel(float *__restrict__ S, const int64_t lds, const int64_t M,
+                                                           const int64_t *__restrict__ ex_rowptr,
+                                                           const int32_t *__restrict__ ex_col,
+                                                           const int64_t *__restrict__ ex_rows, const int k,
+                                                           int32_t *__restrict__ idx_out, float *__restrict__ score_out,
+                                                           const int64_t out_stride) {
+    constexpr int Q = TOPK_REG_ITEMS / 256;
+    __shared__ uint32_t sel_key[TOPK_MAX];
+    __shared__ int32_t sel_idx[TOPK_MAX];
+    __shared__ uint32_t wave_cnt[2][4];
+    __shared__ uint32_t seg_gt[Q * 4], seg_eq[Q * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *row = S + (int64_t)blockIdx.x * lds;
+    if (ex_rowptr) {
+        const int64_t er = ex_rows ? ex_rows[blockIdx.x] : (int64_t)blockIdx.x;
+        const int64_t s = ex_rowptr[er], e = ex_rowptr[er + 1];
+        for (int64_t q = s + tid; q < e; q += 256) {
+            const int c = ex_col[q];
+            if (c >= 0 && c < M) row[c] = -INFINITY;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    uint32_t key[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int i = q * 256 + tid;
+        const float v = row[i < M ? i : (int)M - 1];
+        key[q] = i < M ? order_key(v) : 0u;           // past the row: the lowest key, behind every item of equal key
+        if (q % 8 == 7) __builtin_amdgcn_sched_barrier(0);      // 8 loads in flight; not 64 lane masks alive at once
+    }
+    // 1. the k-th largest key
+    auto count_all = [&](uint32_t c, const int par) {      // sum over the workgroup; two LDS slots by parity: one barrier
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
+        if (lane == 0) wave_cnt[par][wave] = c;
+        __syncthreads();
+        return wave_cnt[par][0] + wave_cnt[par][1] + wave_cnt[par][2] + wave_cnt[par][3];
+    };
+    uint32_t T = 0;
+#pragma unroll 1
+    for (int b = 31; b >= 0; --b) {
+        const uint32_t cand = T | (1u << b);
+        uint32_t c = 0;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) c += key[q] >= cand;
+        if (count_all(c, b & 1) >= (uint32_t)k) T = cand;
+    }
+    uint32_t c = 0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) c += key[q] > T;
+    __syncthreads();
+    const uint32_t n_gt = count_all(c, 0), remaining = (uint32_t)k - n_gt;
+    // 2. ordered compaction: segment (q, wave) = items q 256 + 64 wave .. + 63.  (T is made opaque before each of the
+    // two loops: knowing it to be one value the compiler keeps all 128 lane masks of the comparisons alive from one
+    // loop to the next, in scalar registers it does not have.)
+    asm volatile("" : "+v"(T));
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const unsigned long long bg = __ballot(key[q] > T), be = __ballot(key[q] == T);
+        if (lane == 0) {
+            seg_gt[q * 4 + wave] = (uint32_t)__popcll(bg);
+            seg_eq[q * 4 + wave] = (uint32_t)__popcll(be);
+        }
+        __builtin_amdgcn_sched_barrier(0);         // one segment at a time: 128 lane masks do not fit the scalar registers
+    }
+    __syncthreads();
+    {   // exclusive scan of the Q * 4 = 256 segment counts, one per thread
+        uint32_t g = seg_gt[tid], e = seg_eq[tid];
+        const uint32_t g0 = g, e0 = e;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t tg = __shfl_up(g, o), te = __shfl_up(e, o);
+            if (lane >= o) { g += tg; e += te; }
+        }
+        __syncthreads();                       // every count has been read
+        if (lane == 63) { wave_cnt[0][wave] = g; wave_cnt[1][wave] = e; }
+        __syncthreads();
+        for (int w = 0; w < wave; ++w) { g += wave_cnt[0][w]; e += wave_cnt[1][w]; }
+        seg_gt[tid] = g - g0;
+        seg_eq[tid] = e - e0;
+        __syncthreads();
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    asm volatile("" : "+v"(T));
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const unsigned long long bg = __ballot(key[q] > T), be = __ballot(key[q] == T);
+        if ((bg | be) == 0) continue;              // nearly every segment: nothing of it is selected
+        if (key[q] > T) {
+            const uint32_t p = seg_gt[q * 4 + wave] + (uint32_t)__popcll(bg & below);
+            sel_key[p] = key[q];
+            sel_idx[p] = q * 256 + tid;
+        } else if (key[q] == T) {
+            const uint32_t p = seg_eq[q * 4 + wave] + (uint32_t)__popcll(be & below);
+            if (p < remaining) {
+                sel_key[n_gt + p] = key[q];
+                sel_idx[n_gt + p] = q * 256 + tid;
+            }
+        }
+    }
+    // 3. bitonic sort, descending by (key, -idx)
+    int n2 = 1;
+    while (n2 < k) n2 <<= 1;
+    for (int q = k + tid; q < n2; q += 256) {
+        sel_key[q] = 0u;
+        sel_idx[q] = INT32_MAX;
+    }
+    __syncthreads();
+    for (int size = 2; size <= n2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int q = tid; q < n2 / 2; q += 256) {
+                const int lo = 2 * q - (q & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const uint32_t ka = sel_key[lo], kb = sel_key[hi];
+                const int32_t ia = sel_idx[lo], ib = sel_idx[hi];
+                const bool a_first = (ka > kb) || (ka == kb && ia < ib);   // a ranks before b
+                if (a_first != desc) {
+                    sel_key[lo] = kb; sel_key[hi] = ka;
+                    sel_idx[lo] = ib; sel_idx[hi] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int q = tid; q < k; q += 256) {
+        idx_out[(int64_t)blockIdx.x * out_stride + q] = sel_idx[q];
+        score_out[(int64_t)blockIdx.x * out_stride + q] = key_to_float(sel_key[q]);
+    }
+}
+
 // Final selection of the fused top-k: one workgroup per user sorts the user's candidates
 // (score descending, item id ascending - the order does not depend on the order of arrival)
 // in LDS and writes the first k.
 constexpr int CAND_CAP = 8192;
 // idx_out == nullptr: the first k go back to the head of the candidate row and the row's count
 // becomes k (the row's threshold, slot k-1, tightens for the items still to come).
+// Two instances run one after the other: LCAP = CAND_SMALL takes the rows with at most CAND_SMALL candidates (nearly
+// all: a range adds about 3 k) and the rows to be given up, with 16 KB of LDS - eight workgroups to a CU instead of the
+// two that sorting space for a full row allows; LCAP = CAND_CAP takes the rest (it finds count = k on every row
+// the first instance handled and leaves those alone).
+constexpr int CAND_SMALL = 2048;
+template <int LCAP>
 __global__ __launch_bounds__(256) void select_candidates_kernel(const CandArgs c, int32_t *__restrict__ idx_out,
                                                                float *__restrict__ score_out) {
-    __shared__ uint32_t key[CAND_CAP];
-    __shared__ int32_t item[CAND_CAP];
+    __shared__ uint32_t key[LCAP];
+    __shared__ int32_t item[LCAP];
     float *__restrict__ cscore = c.score;
     int32_t *__restrict__ citem = c.item;
     int32_t *__restrict__ count = c.count;
@@ -590,6 +739,7 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(const CandArgs c
     // all score above the threshold) is given up HERE, alone: its threshold becomes +inf, so that later ranges add
     // nothing to it, and its output row is item -1 throughout - the caller redoes such users by the two-call path.
     const bool dead = count[row] > cap || citem[row * cap] < 0;
+    if (LCAP == CAND_SMALL ? (!dead && count[row] > CAND_SMALL) : (dead || count[row] <= CAND_SMALL)) return;
     if (dead) {
         for (int q = tid; q < k; q += 256) {
             if (idx_out) {
@@ -718,7 +868,88 @@ static bool launch_scores_split(const float *X, int64_t ldx, const int64_t *user
     return true;
 }
 
+// The prepared-table score kernel over items [item_begin, M) (als_scores_prepared.inc).
+static size_t prepared_bytes(int64_t M, int32_t f) {
+    if (M < 1 || f < 1 || f > 128 || f % 4) return 0;
+    const int64_t ks = (f + 31) / 32, stages = (M + 31) / 32;
+    return PREP_HEADER + (size_t)stages * ks * 4096;
+}
+template <bool FILTER>
+static int32_t launch_scores_prepared(const float *X, int64_t ldx, const int64_t *user_ids, int64_t nu, const void *P,
+                                      int64_t M_table, int64_t M, int32_t f, float *S, int64_t lds, int64_t item_begin,
+                                      const CandArgs &cand, hipStream_t st) {
+    if (M <= item_begin) return ALS_OK;
+    const int64_t n_stages = (M - item_begin + 31) / 32;
+    const int64_t nub = (nu + PB_USERS - 1) / PB_USERS;
+    // as launch_scores_split, but about two workgroups per resident slot (512) only: a workgroup's first act is to
+    // load and split its 256 user rows, about as much as 6 stages cost; at least 16 stages each; the chunk count a
+    // multiple of the 8 XCDs so that the workgroups streaming the same items share an L2
+    int64_t n_chunks = std::max<int64_t>(8, (1024 / nub + 7) / 8 * 8);
+    n_chunks = std::min(n_chunks, ((n_stages + 15) / 16 + 7) / 8 * 8);
+    if (n_stages <= 16) n_chunks = 1;
+    const int cpr = n_chunks >= 8 ? 8 : 1;
+    const int64_t per_chunk = (n_stages + n_chunks - 1) / n_chunks;
+    if (n_chunks * nub > 0x7fffffffLL) return als_fail_(ALS_ERR_UNSUPPORTED, "too many users for one prepared-score launch");
+    const dim3 grid((unsigned)(n_chunks * nub)), block(256);
+    const int ks = (f + 31) / 32;
+    const int64_t table_stages = (M_table + 31) / 32;
+    const char *Pc = (const char *)P;
+#define ALS_SCORES_PREP_CASE(n)                                                                                          \
+    if (ks == n)                                                                                                         \
+        hipLaunchKernelGGL((scores_prepared_kernel<n, FILTER>), grid, block, 0, st, X, ldx, user_ids, nu, Pc, M, f, S, lds, \
+                           item_begin, per_chunk, nub, cpr, table_stages, cand);
+    ALS_SCORES_PREP_CASE(1) ALS_SCORES_PREP_CASE(2) ALS_SCORES_PREP_CASE(3) ALS_SCORES_PREP_CASE(4)
+#undef ALS_SCORES_PREP_CASE
+    ALS_HIP_CHECK2(hipGetLastError());
+    return ALS_OK;
+}
+static int32_t check_prepared_args(const char *who, const float *X, int64_t ldx, int64_t nu, const void *P, int64_t M,
+                                   int32_t f) {
+    if (!X || !P) return als_fail_(ALS_ERR_INVALID_ARG, "%s: null pointer", who);
+    if (nu < 1 || M < 1 || f < 1 || ldx < f) return als_fail_(ALS_ERR_INVALID_ARG, "%s: bad sizes (nu=%lld M=%lld f=%d)", who,
+                                                            (long long)nu, (long long)M, f);
+    if (prepared_bytes(M, f) == 0) return als_fail_(ALS_ERR_UNSUPPORTED, "%s: prepared items need f <= 128, f %% 4 == 0", who);
+    if (ldx % 4 || (uintptr_t)X % 16 || (uintptr_t)P % 16)
+        return als_fail_(ALS_ERR_UNSUPPORTED, "%s: user rows and the table must be 16-byte aligned (ldx a multiple of 4)", who);
+    return ALS_OK;
+}
+
 extern "C" {
+
+size_t als_items_prepared_bytes(int64_t M, int32_t f) { return prepared_bytes(M, f); }
+
+int32_t als_items_prepare_f32(const float *Y, int64_t ldy, int64_t M, int32_t f, void *prepared, size_t bytes,
+                              void *stream) {
+    if (!Y || !prepared) return als_fail_(ALS_ERR_INVALID_ARG, "als_items_prepare_f32: null pointer");
+    if (M < 1 || f < 1 || ldy < f) return als_fail_(ALS_ERR_INVALID_ARG, "als_items_prepare_f32: bad sizes");
+    const size_t need = prepared_bytes(M, f);
+    if (need == 0) return als_fail_(ALS_ERR_UNSUPPORTED, "als_items_prepare_f32: f=%d (needs f <= 128, f %% 4 == 0)", f);
+    if (ldy % 4 || (uintptr_t)Y % 16 || (uintptr_t)prepared % 16)
+        return als_fail_(ALS_ERR_UNSUPPORTED, "als_items_prepare_f32: rows and the table must be 16-byte aligned");
+    if (bytes < need) return als_fail_(ALS_ERR_WORKSPACE, "als_items_prepare_f32: table too small: %zu < %zu", bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    ALS_HIP_CHECK2(hipMemsetAsync(prepared, 0, PREP_HEADER, st));
+    const int64_t quads = M * (f / 4);
+    hipLaunchKernelGGL(items_absmax_kernel, dim3((unsigned)std::min<int64_t>(2048, (quads + 255) / 256)), dim3(256), 0, st, Y,
+                       ldy, M, f, (unsigned *)prepared);
+    ALS_HIP_CHECK2(hipGetLastError());
+    const int ks = (f + 31) / 32;
+    const int64_t n_tiles = (M + 31) / 32 * 2, threads = n_tiles * ks * 64;
+    if ((threads + 255) / 256 > 0x7fffffffLL) return als_fail_(ALS_ERR_UNSUPPORTED, "als_items_prepare_f32: too many items");
+    hipLaunchKernelGGL(items_prepare_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, Y, ldy, M, f, ks,
+                       n_tiles, (char *)prepared);
+    ALS_HIP_CHECK2(hipGetLastError());
+    return ALS_OK;
+}
+
+int32_t als_scores_prepared_f32(const float *X, int64_t ldx, const int64_t *user_ids, int64_t nu, const void *prepared,
+                                int64_t M_table, int64_t M, int32_t f, float *scores, int64_t lds, void *stream) {
+    int32_t rc = check_prepared_args("als_scores_prepared_f32", X, ldx, nu, prepared, M_table, f);
+    if (rc) return rc;
+    if (!scores || M < 1 || M > M_table || lds < M) return als_fail_(ALS_ERR_INVALID_ARG, "als_scores_prepared_f32: bad output sizes");
+    const CandArgs none{};
+    return launch_scores_prepared<false>(X, ldx, user_ids, nu, prepared, M_table, M, f, scores, lds, 0, none, (hipStream_t)stream);
+}
 
 int32_t als_scores_f32(const float *X, int64_t ldx, const int64_t *user_ids, int64_t nu, const float *Y, int64_t ldy,
                        int64_t M, int32_t f, float *scores, int64_t lds, void *stream) {
@@ -766,13 +997,14 @@ size_t als_recommend_topk_workspace_bytes(int64_t nu, int64_t M, int32_t k) {
     return b + 256;
 }
 
-int32_t als_recommend_topk_f32(const float *X, int64_t ldx, const int64_t *user_ids, int64_t nu, const float *Y,
-                               int64_t ldy, int64_t M, int32_t f, int32_t k, const int64_t *ex_rowptr,
-                               const int32_t *ex_col, int32_t ex_by_user_id, int32_t *idx_out, float *score_out,
-                               int32_t *overflow_out, void *workspace, size_t ws_bytes, void *stream) {
-    if (!X || !Y || !idx_out || !score_out || !overflow_out || !workspace)
+// Y (with ldy) or a prepared table P of the M items: the same steps either way
+static int32_t recommend_topk_impl(const float *X, int64_t ldx, const int64_t *user_ids, int64_t nu, const float *Y,
+                                   int64_t ldy, const void *P, int64_t M, int32_t f, int32_t k, const int64_t *ex_rowptr,
+                                   const int32_t *ex_col, int32_t ex_by_user_id, int32_t *idx_out, float *score_out,
+                                   int32_t *overflow_out, void *workspace, size_t ws_bytes, void *stream) {
+    if (!X || (!Y && !P) || !idx_out || !score_out || !overflow_out || !workspace)
         return als_fail_(ALS_ERR_INVALID_ARG, "als_recommend_topk_f32: null pointer");
-    if (nu < 1 || M < 1 || M > INT32_MAX || f < 1 || ldx < f || ldy < f)
+    if (nu < 1 || M < 1 || M > INT32_MAX || f < 1 || ldx < f || (Y && ldy < f))
         return als_fail_(ALS_ERR_INVALID_ARG, "als_recommend_topk_f32: bad sizes (nu=%lld M=%lld f=%d)", (long long)nu,
                          (long long)M, f);
     if (k < 1 || k > TOPK_MAX || k > M)
@@ -789,7 +1021,8 @@ int32_t als_recommend_topk_f32(const float *X, int64_t ldx, const int64_t *user_
     char *ws = (char *)workspace;
     float *sub = (float *)ws; ws += align256((size_t)nu * S * sizeof(float));
     // 1. the early items, materialised: scores, exclusions, exact top-k
-    int32_t rc = als_scores_f32(X, ldx, user_ids, nu, Y, ldy, S, f, sub, S, stream);
+    int32_t rc = P ? als_scores_prepared_f32(X, ldx, user_ids, nu, P, M, S, f, sub, S, stream)
+                   : als_scores_f32(X, ldx, user_ids, nu, Y, ldy, S, f, sub, S, stream);
     if (rc) return rc;
     if (S == M) {
         ALS_HIP_CHECK2(hipMemsetAsync(overflow_out, 0, sizeof(int32_t), st));
@@ -803,8 +1036,12 @@ int32_t als_recommend_topk_f32(const float *X, int64_t ldx, const int64_t *user_
     ALS_HIP_CHECK2(hipMemsetAsync(overflow_out, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, st, c.count, nu, k);
     ALS_HIP_CHECK2(hipGetLastError());
-    hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)nu), dim3(256), 0, st, sub, S, S, ex_rowptr, ex_col, ex_rows, k,
-                       c.item, c.score, (int64_t)CAND_CAP);
+    if (S <= TOPK_REG_ITEMS)
+        hipLaunchKernelGGL(topk_rows_reg_kernel, dim3((unsigned)nu), dim3(256), 0, st, sub, S, S, ex_rowptr, ex_col, ex_rows,
+                           k, c.item, c.score, (int64_t)CAND_CAP);
+    else
+        hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)nu), dim3(256), 0, st, sub, S, S, ex_rowptr, ex_col,
+                           ex_rows, k, c.item, c.score, (int64_t)CAND_CAP);
     ALS_HIP_CHECK2(hipGetLastError());
     // 2. the later items, range by range: score tiles are compared with the user's threshold in
     //    registers, never stored; then each user's candidates are ordered and cut back to k
@@ -814,7 +1051,10 @@ int32_t als_recommend_topk_f32(const float *X, int64_t ldx, const int64_t *user_
         int64_t end = (begin > M / FUSED_RANGE_GROWTH) ? M : begin * FUSED_RANGE_GROWTH;
         if (M - end < end / FUSED_RANGE_GROWTH) end = M;      // no short last range
         const dim3 grid((unsigned)((end - begin + 255) / 256), (unsigned)((nu + 63) / 64)), block(256);
-        if (launch_scores_split<true>(X, ldx, user_ids, nu, Y, ldy, end, f, nullptr, 0, begin, c, st)) {
+        if (P) {
+            rc = launch_scores_prepared<true>(X, ldx, user_ids, nu, P, M, end, f, nullptr, 0, begin, c, st);
+            if (rc) return rc;
+        } else if (launch_scores_split<true>(X, ldx, user_ids, nu, Y, ldy, end, f, nullptr, 0, begin, c, st)) {
         } else if (vec)
             hipLaunchKernelGGL((scores_kernel<true, true>), grid, block, 0, st, X, ldx, user_ids, nu, Y, ldy, end, f, nullptr,
                                (int64_t)0, begin, c);
@@ -823,12 +1063,33 @@ int32_t als_recommend_topk_f32(const float *X, int64_t ldx, const int64_t *user_
                                (int64_t)0, begin, c);
         ALS_HIP_CHECK2(hipGetLastError());
         const bool last = end == M;
-        hipLaunchKernelGGL(select_candidates_kernel, dim3((unsigned)nu), dim3(256), 0, st, c, last ? idx_out : nullptr,
-                           last ? score_out : nullptr);
+        hipLaunchKernelGGL(select_candidates_kernel<CAND_SMALL>, dim3((unsigned)nu), dim3(256), 0, st, c,
+                           last ? idx_out : nullptr, last ? score_out : nullptr);
+        hipLaunchKernelGGL(select_candidates_kernel<CAND_CAP>, dim3((unsigned)nu), dim3(256), 0, st, c,
+                           last ? idx_out : nullptr, last ? score_out : nullptr);
         ALS_HIP_CHECK2(hipGetLastError());
         begin = end;
     }
     return ALS_OK;
+}
+
+int32_t als_recommend_topk_f32(const float *X, int64_t ldx, const int64_t *user_ids, int64_t nu, const float *Y,
+                               int64_t ldy, int64_t M, int32_t f, int32_t k, const int64_t *ex_rowptr,
+                               const int32_t *ex_col, int32_t ex_by_user_id, int32_t *idx_out, float *score_out,
+                               int32_t *overflow_out, void *workspace, size_t ws_bytes, void *stream) {
+    if (!Y) return als_fail_(ALS_ERR_INVALID_ARG, "als_recommend_topk_f32: null pointer");
+    return recommend_topk_impl(X, ldx, user_ids, nu, Y, ldy, nullptr, M, f, k, ex_rowptr, ex_col, ex_by_user_id, idx_out,
+                               score_out, overflow_out, workspace, ws_bytes, stream);
+}
+
+int32_t als_recommend_topk_prepared_f32(const float *X, int64_t ldx, const int64_t *user_ids, int64_t nu,
+                                        const void *prepared, int64_t M, int32_t f, int32_t k, const int64_t *ex_rowptr,
+                                        const int32_t *ex_col, int32_t ex_by_user_id, int32_t *idx_out, float *score_out,
+                                        int32_t *overflow_out, void *workspace, size_t ws_bytes, void *stream) {
+    int32_t rc = check_prepared_args("als_recommend_topk_prepared_f32", X, ldx, nu, prepared, M, f);
+    if (rc) return rc;
+    return recommend_topk_impl(X, ldx, user_ids, nu, nullptr, 0, prepared, M, f, k, ex_rowptr, ex_col, ex_by_user_id,
+                               idx_out, score_out, overflow_out, workspace, ws_bytes, stream);
 }
 
 int32_t als_topk_rows_f32(float *scores, int64_t lds, int64_t n_rows, int64_t M, const int64_t *ex_rowptr,
@@ -841,8 +1102,12 @@ int32_t als_topk_rows_f32(float *scores, int64_t lds, int64_t n_rows, int64_t M,
         return als_fail_(ALS_ERR_UNSUPPORTED, "als_topk_rows_f32: k=%d outside [1, min(%d, M)]", k, TOPK_MAX);
     if ((ex_rowptr == nullptr) != (ex_col == nullptr))
         return als_fail_(ALS_ERR_INVALID_ARG, "als_topk_rows_f32: pass both exclusion arrays or neither");
-    hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, scores, lds, M,
-                       ex_rowptr, ex_col, ex_rowptr ? ex_row_ids : nullptr, k, idx_out, score_out, (int64_t)k);
+    if (M <= TOPK_REG_ITEMS)
+        hipLaunchKernelGGL(topk_rows_reg_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, scores, lds, M,
+                           ex_rowptr, ex_col, ex_rowptr ? ex_row_ids : nullptr, k, idx_out, score_out, (int64_t)k);
+    else
+        hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, scores, lds, M,
+                           ex_rowptr, ex_col, ex_rowptr ? ex_row_ids : nullptr, k, idx_out, score_out, (int64_t)k);
     ALS_HIP_CHECK2(hipGetLastError());
     return ALS_OK;
 }

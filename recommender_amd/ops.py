@@ -475,11 +475,44 @@ def half_sweep_cg(csr, Yopp, gram_cache, Xown, alpha, cg_steps, absdiff=None, in
 
 
 # ----------------------------------------------------------------------------- scoring
+class PreparedItems:
+    """An item factor in the operand form of the fp16 matrix cores (als_items_prepare_f32): every value scaled by one
+    power of two and cut into two fp16 pieces, laid out as the score kernel's lanes read it.  Built once per model;
+    scores() and recommend_topk() take it in place of Y and then run three piece products per block instead of six,
+    with no conversion work in the loop (scores to 22 operand bits instead of 24).  Same size as the float32 factor."""
+
+    def __init__(self, table, n_items, f):
+        self.table, self.shape, self.device = table, (int(n_items), int(f)), table.device
+
+
+def prepared_items_supported(f):
+    return lib.als_items_prepared_bytes(1, int(f)) > 0
+
+
+def prepare_items(Y, M=None):
+    """The first M rows (default: all) of the item factor Y as PreparedItems.  f <= 128, f % 4 == 0, 16-byte aligned
+    rows; the factors must be finite."""
+    ldy = _factor_ld(Y, "Y")
+    M = Y.shape[0] if M is None else int(M)
+    f = Y.shape[1]
+    if not (1 <= M <= Y.shape[0]):
+        raise ValueError("M out of range")
+    nbytes = lib.als_items_prepared_bytes(M, f)
+    if nbytes == 0:
+        raise ValueError("prepared items need f <= 128 and f % 4 == 0 (f=%d)" % f)
+    table = torch.empty(nbytes, dtype=torch.uint8, device=Y.device)
+    with torch.cuda.device(Y.device):
+        check(lib.als_items_prepare_f32(_ptr(Y), ldy, M, f, _ptr(table), nbytes, _stream()), "als_items_prepare_f32")
+    return PreparedItems(table, M, f)
+
+
 def scores(X, Y, user_ids=None, M=None, out=None):
     """scores[u, i] = <X[user_ids[u]], Y[i]> for i < M: the [nu, M] matrix that
-    SimpleMFRecAlgo.recommend builds pair by pair (reclibwh/core/RecAlgos.py:20-30)."""
+    SimpleMFRecAlgo.recommend builds pair by pair (reclibwh/core/RecAlgos.py:20-30).  Y: the item factor, or its
+    PreparedItems."""
     ldx = _factor_ld(X, "X")
-    ldy = _factor_ld(Y, "Y")
+    prepared = Y if isinstance(Y, PreparedItems) else None
+    ldy = 0 if prepared else _factor_ld(Y, "Y")
     f = X.shape[1]
     if Y.shape[1] != f:
         raise ValueError("factor counts differ")
@@ -500,10 +533,14 @@ def scores(X, Y, user_ids=None, M=None, out=None):
     _need(out, torch.float32, "out", 2)
     if out.shape[0] < nu or out.shape[1] < M or out.stride(1) != 1:
         raise ValueError("out too small or not row-major")
-    _same_device(X, Y, user_ids, out)
+    _same_device(X, prepared.table if prepared else Y, user_ids, out)
     with torch.cuda.device(X.device):
-        check(lib.als_scores_f32(_ptr(X), ldx, _ptr(user_ids), nu, _ptr(Y), ldy, M, f, _ptr(out), out.stride(0),
-                                 _stream()), "als_scores_f32")
+        if prepared:
+            check(lib.als_scores_prepared_f32(_ptr(X), ldx, _ptr(user_ids), nu, _ptr(prepared.table), prepared.shape[0], M,
+                                              f, _ptr(out), out.stride(0), _stream()), "als_scores_prepared_f32")
+        else:
+            check(lib.als_scores_f32(_ptr(X), ldx, _ptr(user_ids), nu, _ptr(Y), ldy, M, f, _ptr(out), out.stride(0),
+                                     _stream()), "als_scores_f32")
     return out[:nu, :M]
 
 
@@ -595,17 +632,22 @@ def recommend_topk(X, Y, users, k, M=None, exclude_csr=None, block_users=4096, f
     host numpy arrays or device tensors, or a DeviceCSR (the training matrix as it lies on the device).  The kernels
     index it by user id; nothing is built per block.  Returns (idx int32 [nu, k], scores [nu, k]).
 
+    Y: the item factor or its PreparedItems (prepare_items: built once per model, about three times the throughput).
+
     fused=True: als_recommend_topk_f32 - only the first 16 384+ items of a block are materialised,
     the rest is filtered in the score kernel's registers.  Users whose candidate list overflows (the library marks
     their rows: e.g. thousands of excluded items that all score near the top) are redone by the two-call path - they
     alone, not their block -, as is everyone when fused=False."""
-    ldx = _factor_ld(X, "X"); ldy = _factor_ld(Y, "Y")
+    prepared = Y if isinstance(Y, PreparedItems) else None
+    ldx = _factor_ld(X, "X"); ldy = 0 if prepared else _factor_ld(Y, "Y")
     M = Y.shape[0] if M is None else int(M)
     f = X.shape[1]
     if Y.shape[1] != f or not (1 <= M <= Y.shape[0]):
         raise ValueError("factor counts differ or M out of range")
+    if prepared and M != Y.shape[0]:
+        raise ValueError("a prepared item table is ranked whole (prepare_items(Y, M) the rows wanted)")
     _index(users, torch.int64, "users")
-    _same_device(X, Y, users)
+    _same_device(X, prepared.table if prepared else Y, users)
     nu = users.shape[0]
     k = int(k)
     if not (1 <= k <= min(1024, M)):
@@ -628,10 +670,14 @@ def recommend_topk(X, Y, users, k, M=None, exclude_csr=None, block_users=4096, f
         overflow = torch.zeros(len(blocks), dtype=torch.int32, device=X.device)
         for b, (s, e) in enumerate(blocks):
             with torch.cuda.device(X.device):
-                check(lib.als_recommend_topk_f32(_ptr(X), ldx, _ptr(users[s:e]), e - s, _ptr(Y), ldy, M, f, k,
-                                                 _ptr(ex[0]) if ex else None, _ptr(ex[1]) if ex else None, 1,
-                                                 _ptr(idx[s:e]), _ptr(val[s:e]), _ptr(overflow[b:b + 1]), _ptr(ws),
-                                                 ws.numel(), _stream()), "als_recommend_topk_f32")
+                tail = (_ptr(ex[0]) if ex else None, _ptr(ex[1]) if ex else None, 1, _ptr(idx[s:e]), _ptr(val[s:e]),
+                        _ptr(overflow[b:b + 1]), _ptr(ws), ws.numel(), _stream())
+                if prepared:
+                    check(lib.als_recommend_topk_prepared_f32(_ptr(X), ldx, _ptr(users[s:e]), e - s, _ptr(prepared.table),
+                                                              M, f, k, *tail), "als_recommend_topk_prepared_f32")
+                else:
+                    check(lib.als_recommend_topk_f32(_ptr(X), ldx, _ptr(users[s:e]), e - s, _ptr(Y), ldy, M, f, k, *tail),
+                          "als_recommend_topk_f32")
         # users whose candidate list overflowed (marked with item -1) are redone, the others stand; one
         # synchronisation for all blocks
         redo = torch.nonzero(idx[:, 0] < 0).flatten() if bool(overflow.any()) else idx.new_zeros(0, dtype=torch.int64)

@@ -247,7 +247,10 @@ def test_c4_slice_cg_forms_at_f256():
         assert torch.equal(out[form], X4)
 
 
-def test_c5_fused_topk_at_one_million_items():
+@pytest.mark.parametrize("prepared", [False, True])
+def test_c5_fused_topk_at_one_million_items(prepared):
+    """prepared: against the item table in the score kernel's operand form (two fp16 pieces per value), else against
+    the float32 factor (three bf16 pieces)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import recommender_amd as ra
@@ -265,9 +268,10 @@ def test_c5_fused_topk_at_one_million_items():
         full_rows[u] = r
     fptr = np.zeros(4001, dtype=np.int64); np.cumsum([len(r) for r in full_rows], out=fptr[1:])
     ex = (fptr, np.concatenate(full_rows))
-    idx, val = ra.ops.recommend_topk(X, Y, users, k, exclude_csr=ex)
+    T = ra.prepare_items(Y) if prepared else Y
+    idx, val = ra.ops.recommend_topk(X, T, users, k, exclude_csr=ex)
     # the selection done by torch on the library's own scores (same arithmetic, so the same bits)
-    S = ra.scores(X, Y, users)
+    S = ra.scores(X, T, users)
     for j, r in enumerate(ex_rows):
         S[j, torch.from_numpy(r.astype(np.int64)).cuda()] = -float("inf")
     tv, ti = torch.topk(S, k, dim=1, sorted=True)

@@ -27,10 +27,12 @@ def main(argv):
             continue
         key = (name.split("(")[0][-60:], int(r["Grid_Size_X"]) if "Grid_Size_X" in r else int(r.get("Grid_Size", 0)))
         dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-        a = agg.setdefault(key, [0, 0.0, 1e30])
-        a[0] += 1; a[1] += dur; a[2] = min(a[2], dur)
-    for (name, grid), (n, tot, mn) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        print("%-62s grid %10d n=%3d avg %10.1f us min %10.1f us" % (name, grid, n, tot / n, mn))
+        a = agg.setdefault(key, [0, 0.0, 1e30, []])
+        a[0] += 1; a[1] += dur; a[2] = min(a[2], dur); a[3].append(dur)
+    for (name, grid), (n, tot, mn, durs) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        durs.sort()
+        print("%-62s grid %10d n=%3d avg %10.1f us min %10.1f us  median %10.1f max %10.1f" %
+              (name, grid, n, tot / n, mn, durs[len(durs) // 2], durs[-1]))
 
 
 if __name__ == "__main__":

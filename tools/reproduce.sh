@@ -44,4 +44,6 @@ run c3full_exact         --workload c3_full_syn --steps 2 --warmup 1 && \
 run c4shard_cgdef        --workload c4_shard_syn --steps 2 --warmup 1 && \
 run c4shard_cg3          --workload c4_shard_syn --steps 2 --warmup 1 --cg-steps 3 && \
 python3 "$ROOT/tools/bench_topk.py" --users 65536 --skip-materialised && \
-python3 "$ROOT/tools/bench_topk.py" --users 1048576 --filter-rated --skip-materialised && python3 "$ROOT/tools/bench_gram.py"
+python3 "$ROOT/tools/bench_topk.py" --users 65536 --skip-materialised --prepared && \
+python3 "$ROOT/tools/bench_topk.py" --users 1048576 --filter-rated --skip-materialised && \
+python3 "$ROOT/tools/bench_topk.py" --users 1048576 --filter-rated --skip-materialised --prepared && python3 "$ROOT/tools/bench_gram.py"
