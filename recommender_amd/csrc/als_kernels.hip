@@ -1091,7 +1091,7 @@ extern "C" {
 
 const char *als_last_error_string(void) { return g_err; }
 
-int32_t als_abi_version(void) { return 6; }
+int32_t als_abi_version(void) { return 7; }
 
 // ----------------------------------------------------------------------------- plan
 int32_t als_plan_count(const int64_t *rowptr, int64_t n_rows, int32_t chunk_nnz, int64_t *n_items, int64_t *n_long,
