@@ -48,6 +48,21 @@ for case in range(60):
                 else: ra.half_sweep(csr, Y, gc, Xs, alpha, opts=o)
                 got.append(Xs.cpu().numpy())
             if not np.array_equal(got[0], got[1]): flag += "  <-- STREAM != WAVE (cg=%d)" % cg
+    # every accumulate mode, and the short rows in their entry-space form (n_opp >= 16 f: the Gram that is factored is
+    # far from rank deficiency, the condition under which the engine turns these on)
+    for mode in ("bf16x3", "fp16x2", "fp32"):
+        for short in (False, True):
+            if short and not (ra.short_rows_max_entries(f) > 0 and ld % 4 == 0 and M >= 16 * f):
+                continue
+            if mode == "fp16x2" and M < 16 * f:
+                continue
+            Xm = torch.from_numpy(Xh).cuda()[:, :f]
+            info.zero_()
+            if short: ra.whiten(Y, gc, info=info)
+            ra.half_sweep(csr, Y, gc, Xm, alpha, info=info, opts=ra.ops.sweep_opts(accumulate=mode), short_rows=short)
+            e = np.abs(Xm.cpu().numpy().astype(np.float64) - ref).max() / scale
+            worst = max(worst, e / bar)
+            if not (e < bar and int(info.item()) == 0): flag += "  <-- FAIL (%s%s: %.2e)" % (mode, ", short rows" if short else "", e)
     Xg = torch.from_numpy(Xh).cuda()[:, :f]
     ra.half_sweep_cg(csr, Y, gc, Xg, alpha, 3)
     refcg = als_ref.half_sweep_cg(ptr, ind, dat.astype(np.float64), Yh[:, :f].astype(np.float64), Xh[:, :f].astype(np.float64), lamb, alpha, 3)

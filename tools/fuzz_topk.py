@@ -24,6 +24,13 @@ for case in range(40):
     i0, v0 = ra.ops.recommend_topk(X, Y, users, k, exclude_csr=ex, fused=False)
     i1, v1 = ra.ops.recommend_topk(X, Y, users, k, exclude_csr=ex, block_users=int(rng.choice([64, 4096])))
     ok = torch.equal(i0, i1) and torch.equal(v0, v1)
+    if f <= 128 and f % 4 == 0:            # the same against the prepared item table
+        P = ra.prepare_items(Y)
+        j0, w0 = ra.ops.recommend_topk(X, P, users, k, exclude_csr=ex, fused=False)
+        j1, w1 = ra.ops.recommend_topk(X, P, users, k, exclude_csr=ex, block_users=int(rng.choice([64, 4096])))
+        ok = ok and torch.equal(j0, j1) and torch.equal(w0, w1)
+        # and the two arithmetics rank alike wherever scores are clearly apart: the k-th scores agree to rounding
+        ok = ok and bool(((w0[:, -1] - v0[:, -1]).abs() <= 1e-5 * v0[:, 0].abs().clamp_min(1e-30)).all())
     bad += not ok
     print(case, "f", f, "M", M, "nu", nu, "k", k, "ld", ld, "ex", ex is not None, "ok" if ok else "MISMATCH", flush=True)
 print("MISMATCHES", bad)
