@@ -240,6 +240,15 @@ def main():
     rp, yp = get_pos_ratings_padded(U, users, U.shape[1])
     out.update(users=users, rp=rp.astype(np.float64), yp=yp.astype(np.int64), pad_val=np.int64(U.shape[1]))
     np.savez_compressed(os.path.join(HERE, "g6_padded_batch.npz"), **out)
+    # ---- G7: the saved-run folder of a finished reference ALS run as the reference's repository holds it
+    # (deploy/ALS_2020-12-16.15-48-46-serve: algorithm_config.json written by ALS.py:283, eval.csv by
+    # EvalProto.py:74-94): two small data files, copied as they are
+    import shutil
+    src = os.path.join(args.ref, "deploy", "ALS_2020-12-16.15-48-46-serve")
+    dst = os.path.join(HERE, "ref_deploy_als")
+    os.makedirs(dst, exist_ok=True)
+    for name in ("algorithm_config.json", "eval.csv"):
+        shutil.copyfile(os.path.join(src, name), os.path.join(dst, name))
     print("golden vectors written to", HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"): print("  %-28s %8d bytes" % (f, os.path.getsize(os.path.join(HERE, f))))
