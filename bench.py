@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--short-rows", default="auto", choices=["auto", "on", "off"],
                     help="exact solver, 32 < f <= 128: rows with fewer stored entries than factors solved in their "
                          "entry-space form (auto: where it pays, see recommender_amd/als.py::short_rows_pay)")
+    ap.add_argument("--reserve-cus", type=int, default=None,
+                    help="multi-GPU, 64 < f <= 128: compute units the persistent row kernel leaves free for the RCCL "
+                         "exchange that runs beside it (default: the engine's choice, 16; 0 = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="only the headline measurement")
     ap.add_argument("--also-steps", type=int, default=3)
@@ -201,7 +204,7 @@ class Ctx:
 
 
 def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel, steps, warmup, shards=None,
-            short_rows="auto"):
+            short_rows="auto", reserve_cus=None):
     """Builds (or reuses) the shards of `workload`, runs warmup + `steps` timed iterations and returns
     (result dict, shards, host init or None).  Every per-row kernel of every half-sweep is bracketed by
     events the library records on the launch stream (als_sweep_opts_t.tap_begin/tap_end)."""
@@ -236,7 +239,7 @@ def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel,
                           chunk_nnz=2048 * (1 if int(wl.get("blocks", world)) == 1 else 4))
     eng = ALSEngine(csr_u, csr_i, X, Y, wl["lamb"], wl["alpha"], ub, ib, group, solver=solver,
                     cg_steps=cg_steps, cg_form=cg_form, short_rows={"auto": "auto", "on": True, "off": False}[short_rows]
-                    if solver != "cg" else False)
+                    if solver != "cg" else False, stream_reserve_cus=reserve_cus)
     short = dict(eng.short)
     cg = solver == "cg"
     lockstep = cg and (cg_form == "lock_step" or (cg_form == "auto" and f > 128))
@@ -326,6 +329,7 @@ def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel,
         "short_rows": short_rows_note(short, csr_u, csr_i, f),
     }
     if exposed is not None:
+        exposed["stream_reserve_cus"] = eng.stream_reserve_cus
         res["exchange"] = exposed
     if "blocks" in wl:
         res["scaling"] = strong_scaling(workload, f, solver, world, dt / steps * 1e3)
@@ -657,7 +661,7 @@ def main():
         return
     head, shards, (Xh, Yh, wl) = measure(ctx, args.workload, args.factors, args.solver, args.cg_steps, args.cg_form,
                                          args.accumulate, args.row_kernel, args.steps, args.warmup,
-                                         short_rows=args.short_rows)
+                                         short_rows=args.short_rows, reserve_cus=args.reserve_cus)
     f = head["f"]
     cg = head["solver"] == "cg"
 
@@ -676,7 +680,8 @@ def main():
         for (wname, ff, solver, sh, cgs) in plan:
             try:
                 r, prev, _ = measure(ctx, wname, ff, solver, cgs if cgs > 0 else args.cg_steps, "auto", args.accumulate, args.row_kernel,
-                                     args.also_steps, 1, shards=prev if sh == "prev" else sh, short_rows=args.short_rows)
+                                     args.also_steps, 1, shards=prev if sh == "prev" else sh, short_rows=args.short_rows,
+                                     reserve_cus=args.reserve_cus)
                 also.append({"workload": r["workload"], "f": r["f"], "solver": r["solver"], "cg_steps": r["cg_steps"],
                              "steps": r["steps"],
                              "nnz_per_s": r["value"], "ms_per_step": r["ms_per_step"], "launch_ms": r["launch_ms"],

@@ -82,7 +82,12 @@ int32_t als_abi_version(void);
  *       them; the final |delta| reduction lies outside).
  *   whitened / ld_whitened / short_bounds  all NULL / 0: every row is solved as an f x f system.  Given (exact
  *       half-sweep, 32 < f <= 128, f % 4 == 0): rows with at most min(f, 128) (f <= 64: 64) stored entries are
- *       solved in their entry-space form, see "Short rows" below. */
+ *       solved in their entry-space form, see "Short rows" below.
+ *   reserve_cus  0: the STREAM row kernel keeps one wavefront resident on every SIMD of the device (4 per compute
+ *       unit), each holding all of its SIMD's vector registers - until it ends nothing else can start anywhere on
+ *       the chip.  n > 0: it leaves the SIMDs of n compute units free (grid = 4 (CUs - n) wavefronts), so that
+ *       kernels of other streams - the RCCL all-gather of the previous row chunk in a multi-GPU run - can run beside
+ *       it.  The rows are shared out by the grid size and solved independently: the results are the same bits. */
 #define ALS_ACCUMULATE_DEFAULT 0
 #define ALS_ACCUMULATE_BF16X3 1
 #define ALS_ACCUMULATE_FP32 2
@@ -100,6 +105,7 @@ typedef struct {
     const float *whitened;       /* [device] table of als_whiten_f32 for Yopp, or NULL (see "Short rows" below)  */
     int64_t ld_whitened;         /* its leading dimension (>= 2 f, a multiple of 4)                              */
     const int64_t *short_bounds; /* [host] the ALS_SHORT_MAX_GROUPS + 2 entries of als_plan_short_bounds         */
+    int32_t reserve_cus;         /* compute units the STREAM row kernel leaves free, 0 = none                     */
 } als_sweep_opts_t;
 
 /* ------------------------------------------------------------------------------------

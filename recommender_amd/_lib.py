@@ -23,6 +23,7 @@ MAX_FACTORS = 256
 MAX_FACTORS_EXACT = 128
 GRAM_WIDE_CHUNK_ROWS = 4096
 SHORT_MAX_GROUPS = 8
+ABI_VERSION = 8          # als_abi_version() of the library this binding is written for (struct layouts included)
 ACCUMULATE_MODES = {"default": 0, "bf16x3": 1, "fp32": 2, "fp16x2": 3}
 ROW_KERNELS = {"auto": 0, "wave": 1, "stream": 2}
 CG_FORMS = {"auto": 0, "lock_step": 1, "matrix": 2}
@@ -75,7 +76,8 @@ SIGNATURES = {
 class SweepOpts(ctypes.Structure):
     """als_sweep_opts_t of include/als_hip.h."""
     _fields_ = [("accumulate", c_i32), ("row_kernel", c_i32), ("tap_begin", c_vp), ("tap_end", c_vp),
-                ("max_rating", c_f32), ("whitened", c_vp), ("ld_whitened", c_i64), ("short_bounds", c_vp)]
+                ("max_rating", c_f32), ("whitened", c_vp), ("ld_whitened", c_i64), ("short_bounds", c_vp),
+                ("reserve_cus", c_i32)]
 
 
 class AlsHipError(RuntimeError):
@@ -92,6 +94,9 @@ def _load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if lib.als_abi_version() != ABI_VERSION:
+        raise ImportError("recommender_amd: %s has ABI version %d, this binding needs %d - rebuild the extension "
+                          "(__graft_entry__.build())" % (LIB_PATH, lib.als_abi_version(), ABI_VERSION))
     return lib
 
 

@@ -222,7 +222,7 @@ class ALSEngine:
 
     def __init__(self, csr_users, csr_items, X, Y, lamb, alpha, user_bounds=None, item_bounds=None, group=None,
                  backend=ops, overlap_chunks=None, solver="auto", cg_steps=None, cg_form="auto", short_rows="auto",
-                 uneven_exchange="padded"):
+                 uneven_exchange="padded", stream_reserve_cus=None):
         self.group = group
         if uneven_exchange not in UNEVEN_FORMS:
             raise ValueError("uneven_exchange must be one of %s" % (UNEVEN_FORMS,))
@@ -282,6 +282,15 @@ class ALSEngine:
         self.overlap_chunks = max(1, int(overlap_chunks))      # the same on every rank
         self._user_parts = None
         self._side = None
+        # The persistent row kernel of 64 < f <= 128 holds every SIMD's registers until it ends: an RCCL kernel that
+        # becomes ready meanwhile - the exchange of the previous row chunk - would start only behind it, and the
+        # overlap the chunks exist for would shrink to the other kernels' share of a chunk.  In a chunked multi-GPU
+        # sweep it therefore leaves the SIMDs of a few compute units free (als_sweep_opts_t.reserve_cus; the results do
+        # not depend on it).  16 of 256 compute units is a choice made without multi-GPU hardware at hand.
+        if stream_reserve_cus is None:
+            stream_reserve_cus = 16 if (self.world > 1 and self.overlap_chunks > 1 and X.is_cuda
+                                        and not _host_staged(X, group)) else 0
+        self.stream_reserve_cus = int(stream_reserve_cus)
         # benchmarks set this to {"x_wait": [], "y_gather": []}: per step, event pairs around the main stream's wait for
         # the user exchange still in flight when the user sweep has been queued, and around the item exchange
         self.exchange_taps = None
@@ -346,9 +355,13 @@ class ALSEngine:
         done = []
         for c, (r0, r1, csr, dbuf) in enumerate(parts):
             if csr is not None:
+                opts = self.sweep_opts("users") if self.sweep_opts else None
+                if chunked and self.stream_reserve_cus and self.backend is ops:
+                    if opts is None:
+                        opts = ops.sweep_opts()
+                    opts.reserve_cus = self.stream_reserve_cus
                 run_als_epoch(csr, self.X[u0 + r0:u0 + r1], self.Y, self.cache_Y, self.alpha, dbuf, self.info,
-                              self.backend, self.cg_steps, self.cg_form, self.sweep_opts("users") if self.sweep_opts else None,
-                              self.short["users"])
+                              self.backend, self.cg_steps, self.cg_form, opts, self.short["users"])
             else:
                 dbuf.zero_()
             if not chunked:

@@ -913,11 +913,14 @@ struct SweepOpts {
     const float *whitened;      // table of als_whiten_f32 for the fixed factor, or null: no short-row form
     int64_t ldw;
     const int64_t *bounds;      // host: als_plan_short_bounds
+    int reserve_cus;            // compute units the stream kernel leaves to other streams
 };
 inline int32_t read_opts(const als_sweep_opts_t *o, SweepOpts &out) {
     out.split = true; out.f16 = false; out.f16_auto = false; out.rmax = 0.f; out.row_kernel = ALS_ROW_KERNEL_AUTO; out.tap0 = out.tap1 = nullptr;
-    out.whitened = nullptr; out.ldw = 0; out.bounds = nullptr;
+    out.whitened = nullptr; out.ldw = 0; out.bounds = nullptr; out.reserve_cus = 0;
     if (!o) return ALS_OK;
+    if (o->reserve_cus < 0) return fail(ALS_ERR_INVALID_ARG, "als_sweep_opts_t: reserve_cus must be >= 0");
+    out.reserve_cus = o->reserve_cus;
     if (o->accumulate != ALS_ACCUMULATE_DEFAULT && o->accumulate != ALS_ACCUMULATE_FP32 &&
         o->accumulate != ALS_ACCUMULATE_BF16X3 && o->accumulate != ALS_ACCUMULATE_FP16X2)
         return fail(ALS_ERR_INVALID_ARG, "als_sweep_opts_t: unknown accumulate mode %d", o->accumulate);
@@ -995,11 +998,13 @@ static int32_t half_sweep_impl(const SweepParams &p, int64_t n_rows, int64_t n_i
             ALS_HIP_CHECK(hipGetDevice(&dev));
             ALS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
             cus = std::max(cus, 1);
+            // resident waves: one per SIMD, but for the compute units the caller wants left to other streams
+            const int64_t waves = 4 * (int64_t)std::max(cus - o.reserve_cus, 1);
             // The chunk items of long rows: as streams too once every resident wave gets several of them (their static
             // shares are then even; with few, the one-wave kernel's workgroups, handed out as SIMDs fall free, balance
             // better).  Same partial sums bit for bit either way.
             if (n_chunk_items >= ALS_STREAM_CHUNKS_MIN_PER_WAVE * 4 * (int64_t)cus) {
-                const dim3 grid((unsigned)(4 * cus)), block(64);
+                const dim3 grid((unsigned)waves), block(64);
                 if (o.f16) {
                     if (p.f == 128) hipLaunchKernelGGL((sweep_stream_kernel<true, true, true>), grid, block, 0, st, p, (int64_t)0, n_chunk_items);
                     else hipLaunchKernelGGL((sweep_stream_kernel<false, true, true>), grid, block, 0, st, p, (int64_t)0, n_chunk_items);
@@ -1020,7 +1025,7 @@ static int32_t half_sweep_impl(const SweepParams &p, int64_t n_rows, int64_t n_i
                 ALS_HIP_CHECK(hipGetLastError());
             }
             if (n_whole > 0) {
-                const dim3 grid((unsigned)std::min<int64_t>(n_whole, 4 * (int64_t)cus)), block(64);      // one wave per SIMD
+                const dim3 grid((unsigned)std::min<int64_t>(n_whole, waves)), block(64);      // one wave per SIMD
                 if (o.f16) {
                     if (p.f == 128) hipLaunchKernelGGL((sweep_stream_kernel<true, false, true>), grid, block, 0, st, p, n_chunk_items, n_whole);
                     else hipLaunchKernelGGL((sweep_stream_kernel<false, false, true>), grid, block, 0, st, p, n_chunk_items, n_whole);
@@ -1091,7 +1096,7 @@ extern "C" {
 
 const char *als_last_error_string(void) { return g_err; }
 
-int32_t als_abi_version(void) { return 7; }
+int32_t als_abi_version(void) { return 8; }
 
 // ----------------------------------------------------------------------------- plan
 int32_t als_plan_count(const int64_t *rowptr, int64_t n_rows, int32_t chunk_nnz, int64_t *n_items, int64_t *n_long,

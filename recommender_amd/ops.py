@@ -60,18 +60,23 @@ def _factor_ld(t, name):
     return t.stride(0)
 
 
-def sweep_opts(accumulate="default", row_kernel="auto", tap=None):
+def sweep_opts(accumulate="default", row_kernel="auto", tap=None, reserve_cus=0):
     """Per-call options of the half-sweeps (als_sweep_opts_t).
     accumulate: "fp16x2" (= "default" for a DeviceCSR, which knows its largest rating: operands scaled by a power of
     two and cut into two fp16 pieces, three piece products on the fp16 matrix cores), "bf16x3" (three bf16 pieces,
     six products) or "fp32" (float32 matrix-core fma chain).
     row_kernel: "auto", "wave" or "stream" - which per-row kernel handles 64 < f <= 128.
-    tap: (begin, end) torch.cuda.Event pair recorded around the call's per-row kernels."""
+    tap: (begin, end) torch.cuda.Event pair recorded around the call's per-row kernels.
+    reserve_cus: compute units the persistent stream kernel leaves free for kernels of other streams (the RCCL
+    exchange of a multi-GPU run); the results do not depend on it."""
     if accumulate not in _lib.ACCUMULATE_MODES:
         raise ValueError("accumulate must be one of %s" % sorted(_lib.ACCUMULATE_MODES))
     if row_kernel not in _lib.ROW_KERNELS:
         raise ValueError("row_kernel must be one of %s" % sorted(_lib.ROW_KERNELS))
-    o = _lib.SweepOpts(accumulate=_lib.ACCUMULATE_MODES[accumulate], row_kernel=_lib.ROW_KERNELS[row_kernel])
+    if int(reserve_cus) < 0:
+        raise ValueError("reserve_cus must be >= 0")
+    o = _lib.SweepOpts(accumulate=_lib.ACCUMULATE_MODES[accumulate], row_kernel=_lib.ROW_KERNELS[row_kernel],
+                       reserve_cus=int(reserve_cus))
     if tap is not None:
         o.tap_begin, o.tap_end = tap[0].cuda_event, tap[1].cuda_event
         o._tap = tap            # keeps the events alive, and lets a call made of several library calls record them itself
@@ -373,6 +378,7 @@ def half_sweep(csr, Yopp, gram_cache, Xown, alpha, absdiff=None, info=None, opts
     o = _lib.SweepOpts()
     if opts is not None:
         o.accumulate, o.row_kernel, o.tap_begin, o.tap_end = opts.accumulate, opts.row_kernel, opts.tap_begin, opts.tap_end
+        o.reserve_cus = opts.reserve_cus
     o.max_rating = csr.max_rating          # the bound the fp16 x 2 accumulate (the default) takes its scale from
     o._keep = (opts,)
     opts = o
@@ -458,6 +464,7 @@ def half_sweep_cg(csr, Yopp, gram_cache, Xown, alpha, cg_steps, absdiff=None, in
     o = _lib.SweepOpts()
     if opts is not None:
         o.accumulate, o.row_kernel, o.tap_begin, o.tap_end = opts.accumulate, opts.row_kernel, opts.tap_begin, opts.tap_end
+        o.reserve_cus = opts.reserve_cus
     o.max_rating = csr.max_rating          # the formed-matrix form accumulates as the exact half-sweep does
     o._keep = (opts,)
     opts = o

@@ -198,3 +198,39 @@ def test_a_non_finite_row_nobody_references_changes_nothing(f):
         finite, nan = run(0.25, **dict(kw)), run(float("nan"), **dict(kw))
         assert np.all(np.isfinite(nan)), kw
         assert np.array_equal(finite, nan), kw
+
+
+@pytest.mark.parametrize("f", [128, 100])
+def test_reserved_compute_units_change_nothing_but_the_grid(f):
+    """als_sweep_opts_t.reserve_cus: the stream kernel leaves compute units free for other streams (the RCCL exchange
+    of a multi-GPU run).  Rows are shared out by the grid size and solved independently: with 16 units reserved, and
+    with all but one (four resident wavefronts walk every row), factors and |delta| are the bits of the full grid -
+    whole rows and the long rows' chunk items alike."""
+    import recommender_amd as ra
+
+    rng = np.random.default_rng(31 + f)
+    N, M, chunk = 2600, 5000, 64
+    lens = rng.integers(0, 90, size=N).astype(np.int64)
+    long_rows = rng.choice(N, size=160, replace=False)
+    lens[long_rows] = rng.integers(2000, 2100, size=160)          # ~5 000 chunk items: they take the stream kernel too
+    ptr = np.zeros(N + 1, dtype=np.int64)
+    np.cumsum(lens, out=ptr[1:])
+    ind = np.concatenate([np.sort(rng.choice(M, size=l, replace=False)) for l in lens]).astype(np.int32)
+    dat = (rng.integers(1, 11, size=ptr[-1]) * 0.5).astype(np.float32)
+    Y = torch.from_numpy(rng.normal(0, 1 / np.sqrt(f), size=(M, f)).astype(np.float32)).cuda()
+    X0 = torch.from_numpy(rng.normal(0, 1 / np.sqrt(f), size=(N, f)).astype(np.float32)).cuda()
+    csr = ra.DeviceCSR(ptr, ind, dat, (N, M), "cuda", chunk_nnz=chunk)
+    gc = ra.gram(Y, 0.01)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    out = []
+    for reserve in (0, 16, cus - 1, 10 * cus):
+        X = X0.clone()
+        info = torch.zeros(1, dtype=torch.int32, device="cuda")
+        d = ra.half_sweep(csr, Y, gc, X, 40.0, info=info, opts=ra.ops.sweep_opts(row_kernel="stream", reserve_cus=reserve))
+        torch.cuda.synchronize()
+        assert int(info.item()) == 0
+        out.append((X, float(d.item())))
+    for X, d in out[1:]:
+        assert torch.equal(X, out[0][0]) and d == out[0][1]
+    with pytest.raises(ValueError):
+        ra.ops.sweep_opts(reserve_cus=-1)
