@@ -68,7 +68,7 @@ def parse():
                          "entry-space form (auto: where it pays, see recommender_amd/als.py::short_rows_pay)")
     ap.add_argument("--reserve-cus", type=int, default=None,
                     help="multi-GPU, 64 < f <= 128: compute units the persistent row kernel leaves free for the RCCL "
-                         "exchange that runs beside it (default: the engine's choice, 16; 0 = none)")
+                         "exchange that runs beside it (default: the engine's choice, one eighth of them; 0 = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="only the headline measurement")
     ap.add_argument("--also-steps", type=int, default=3)

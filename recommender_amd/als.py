@@ -282,14 +282,17 @@ class ALSEngine:
         self.overlap_chunks = max(1, int(overlap_chunks))      # the same on every rank
         self._user_parts = None
         self._side = None
-        # The persistent row kernel of 64 < f <= 128 holds every SIMD's registers until it ends: an RCCL kernel that
-        # becomes ready meanwhile - the exchange of the previous row chunk - would start only behind it, and the
-        # overlap the chunks exist for would shrink to the other kernels' share of a chunk.  In a chunked multi-GPU
-        # sweep it therefore leaves the SIMDs of a few compute units free (als_sweep_opts_t.reserve_cus; the results do
-        # not depend on it).  16 of 256 compute units is a choice made without multi-GPU hardware at hand.
+        # The persistent row kernel of 64 < f <= 128 holds every SIMD's registers until it ends: a kernel of another
+        # stream that becomes ready meanwhile - the RCCL exchange of the previous row chunk - starts only behind it, and
+        # the overlap the chunks exist for shrinks to the other kernels' share of a chunk.  In a chunked multi-GPU sweep
+        # it therefore leaves compute units free (als_sweep_opts_t.reserve_cus; the results do not depend on it) in
+        # every chunk that has an exchange running beside it, i.e. all but the first.  How many: measured on one
+        # MI355X (tools/overlap_probe.py), a kernel with workgroups of several waves is dispatched only when EVERY
+        # shader engine has a wholly free compute unit - with 32 engines of 8 units, 31 free units are as good as none,
+        # 32 let a 256-thread kernel run at once - hence one eighth of the units.
         if stream_reserve_cus is None:
-            stream_reserve_cus = 16 if (self.world > 1 and self.overlap_chunks > 1 and X.is_cuda
-                                        and not _host_staged(X, group)) else 0
+            rccl = self.world > 1 and self.overlap_chunks > 1 and X.is_cuda and not _host_staged(X, group)
+            stream_reserve_cus = torch.cuda.get_device_properties(X.device).multi_processor_count // 8 if rccl else 0
         self.stream_reserve_cus = int(stream_reserve_cus)
         # benchmarks set this to {"x_wait": [], "y_gather": []}: per step, event pairs around the main stream's wait for
         # the user exchange still in flight when the user sweep has been queued, and around the item exchange
@@ -356,7 +359,7 @@ class ALSEngine:
         for c, (r0, r1, csr, dbuf) in enumerate(parts):
             if csr is not None:
                 opts = self.sweep_opts("users") if self.sweep_opts else None
-                if chunked and self.stream_reserve_cus and self.backend is ops:
+                if chunked and c > 0 and self.stream_reserve_cus and self.backend is ops:
                     if opts is None:
                         opts = ops.sweep_opts()
                     opts.reserve_cus = self.stream_reserve_cus

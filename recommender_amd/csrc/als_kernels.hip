@@ -998,13 +998,14 @@ static int32_t half_sweep_impl(const SweepParams &p, int64_t n_rows, int64_t n_i
             ALS_HIP_CHECK(hipGetDevice(&dev));
             ALS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
             cus = std::max(cus, 1);
-            // resident waves: one per SIMD, but for the compute units the caller wants left to other streams
-            const int64_t waves = 4 * (int64_t)std::max(cus - o.reserve_cus, 1);
+            // resident waves: one per SIMD - a workgroup of four per compute unit -, but for the compute units the caller
+            // wants left to other streams
+            const int64_t waves = STREAM_WG_WAVES * (int64_t)std::max(cus - o.reserve_cus, 1);
             // The chunk items of long rows: as streams too once every resident wave gets several of them (their static
             // shares are then even; with few, the one-wave kernel's workgroups, handed out as SIMDs fall free, balance
             // better).  Same partial sums bit for bit either way.
             if (n_chunk_items >= ALS_STREAM_CHUNKS_MIN_PER_WAVE * 4 * (int64_t)cus) {
-                const dim3 grid((unsigned)waves), block(64);
+                const dim3 grid((unsigned)(waves / STREAM_WG_WAVES)), block(64 * STREAM_WG_WAVES);
                 if (o.f16) {
                     if (p.f == 128) hipLaunchKernelGGL((sweep_stream_kernel<true, true, true>), grid, block, 0, st, p, (int64_t)0, n_chunk_items);
                     else hipLaunchKernelGGL((sweep_stream_kernel<false, true, true>), grid, block, 0, st, p, (int64_t)0, n_chunk_items);
@@ -1025,7 +1026,7 @@ static int32_t half_sweep_impl(const SweepParams &p, int64_t n_rows, int64_t n_i
                 ALS_HIP_CHECK(hipGetLastError());
             }
             if (n_whole > 0) {
-                const dim3 grid((unsigned)std::min<int64_t>(n_whole, waves)), block(64);      // one wave per SIMD
+                const dim3 grid((unsigned)ceil_div(std::min<int64_t>(n_whole, waves), STREAM_WG_WAVES)), block(64 * STREAM_WG_WAVES);
                 if (o.f16) {
                     if (p.f == 128) hipLaunchKernelGGL((sweep_stream_kernel<true, false, true>), grid, block, 0, st, p, n_chunk_items, n_whole);
                     else hipLaunchKernelGGL((sweep_stream_kernel<false, false, true>), grid, block, 0, st, p, n_chunk_items, n_whole);

@@ -3,17 +3,21 @@
 The multi-GPU engine issues the all-gather of row chunk c on a side stream while the sweep of chunk c + 1 runs.
 sweep_stream_kernel (64 < f <= 128) keeps one wavefront with all 512 registers on every SIMD, so a kernel that
 becomes ready beside it should find no room until it ends - unless the sweep leaves compute units free
-(als_sweep_opts_t.reserve_cus).  This probe measures exactly that on one GPU, with a device-to-device copy kernel
-standing in for the collective: user half-sweep of the 1.25 M x 1 M block (f = 128) on the main stream, a copy of
-`--mb` megabytes on a side stream that may start when the sweep starts; reported per reserve_cus: the sweep's
-duration and the time from the sweep's start to the copy's end (alone, the copy takes `copy_alone_ms`).
+(als_sweep_opts_t.reserve_cus).  This probe measures exactly that on one GPU, with a copy kernel standing in for the
+collective: user half-sweep of the 1.25 M x 1 M block (f = 128) on the main stream, a copy of `--mb` megabytes on a
+side stream submitted `--delay-ms` after the sweep was queued, i.e. while its persistent kernel runs; reported per reserve_cus: the sweep's duration and the time from
+the sweep's start to the copy's end (alone, the copy takes `copy_alone_ms`).  Two stand-ins: the runtime's own copy
+kernel (a handful of registers: it fits into the 40 registers the stream kernel leaves on a SIMD) and
+tools/ubench/probe_copy.hip with the footprint of an RCCL kernel (`--blocks` workgroups of 256 threads, 128 vector
+registers, 16 KB of LDS), built with the hipcc line in that file.
 
-    python tools/overlap_probe.py [--reserve 0 4 8 16 32] [--mb 640]
+    python tools/overlap_probe.py [--reserve 0 4 8 16 32] [--mb 640] [--blocks 32]
 """
 import argparse
 import json
 import os
 import sys
+import time
 
 import torch
 
@@ -25,6 +29,10 @@ def main():
     ap.add_argument("--reserve", type=int, nargs="*", default=[0, 4, 8, 16, 32])
     ap.add_argument("--mb", type=int, default=640)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--blocks", type=int, default=32)
+    ap.add_argument("--threads", type=int, default=256, help="threads per workgroup of the stand-in (64, 128 or 256)")
+    ap.add_argument("--delay-ms", type=float, default=4.0,
+                    help="host-side wait between queueing the sweep and the copy (the sweep takes 20-30 ms)")
     args = ap.parse_args()
     from recommender_amd import data, ops
     dev = torch.device("cuda", 0)
@@ -44,12 +52,26 @@ def main():
     side = torch.cuda.Stream(device=dev)
     main_s = torch.cuda.current_stream(dev)
     ev = lambda: torch.cuda.Event(enable_timing=True)
-    # the copy alone
-    dst.copy_(src); torch.cuda.synchronize()
-    a, b = ev(), ev()
-    a.record(); dst.copy_(src); b.record(); torch.cuda.synchronize()
-    out = {"copy_mb": args.mb, "copy_alone_ms": a.elapsed_time(b), "runs": []}
-    for short in (True, False):
+    import ctypes
+    probe = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ubench", "libprobe_copy.so"))
+    probe.probe_copy_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_void_p]
+
+    def copy(kind):
+        if kind == "runtime":
+            dst.copy_(src)
+        else:
+            rc = probe.probe_copy_launch(src.data_ptr(), dst.data_ptr(), src.numel(), args.blocks, args.threads,
+                                         torch.cuda.current_stream(dev).cuda_stream)
+            assert rc == 0, rc
+
+    out = {"copy_mb": args.mb, "blocks": args.blocks, "threads": args.threads, "delay_ms": args.delay_ms, "runs": []}
+    for kind in ("runtime", "rccl_like"):
+        copy(kind); torch.cuda.synchronize()
+        a, b = ev(), ev()
+        a.record(); copy(kind); b.record(); torch.cuda.synchronize()
+        out["copy_alone_ms_" + kind] = a.elapsed_time(b)
+    for kind, short in (("runtime", True), ("rccl_like", True), ("rccl_like", False)):
         for res in args.reserve:
             best = None
             for _ in range(args.reps + 1):
@@ -60,13 +82,15 @@ def main():
                 side.wait_event(e0)
                 ops.half_sweep(csr, Y, cache, X, wl["alpha"], opts=ops.sweep_opts(reserve_cus=res), short_rows=short)
                 e1.record(main_s)
+                time.sleep(args.delay_ms * 1e-3)      # the copy is submitted while the persistent kernel is running
                 with torch.cuda.stream(side):
-                    dst.copy_(src)
+                    copy(kind)
                     c1.record(side)
                 torch.cuda.synchronize()
                 t = (e0.elapsed_time(e1), e0.elapsed_time(c1))
                 best = t if best is None or t[1] < best[1] else best      # the first pass warms up
-            out["runs"].append({"short_rows": short, "reserve_cus": res, "sweep_ms": best[0], "copy_done_after_ms": best[1]})
+            out["runs"].append({"copy": kind, "short_rows": short, "reserve_cus": res, "sweep_ms": best[0],
+                                "copy_done_after_ms": best[1]})
             print(json.dumps(out["runs"][-1]), flush=True)
     print(json.dumps(out))
 
