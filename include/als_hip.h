@@ -83,11 +83,13 @@ int32_t als_abi_version(void);
  *   whitened / ld_whitened / short_bounds  all NULL / 0: every row is solved as an f x f system.  Given (exact
  *       half-sweep, 32 < f <= 128, f % 4 == 0): rows with at most min(f, 128) (f <= 64: 64) stored entries are
  *       solved in their entry-space form, see "Short rows" below.
- *   reserve_cus  0: the STREAM row kernel keeps one wavefront resident on every SIMD of the device (4 per compute
- *       unit), each holding all of its SIMD's vector registers - until it ends nothing else can start anywhere on
- *       the chip.  n > 0: it leaves the SIMDs of n compute units free (grid = 4 (CUs - n) wavefronts), so that
- *       kernels of other streams - the RCCL all-gather of the previous row chunk in a multi-GPU run - can run beside
- *       it.  The rows are shared out by the grid size and solved independently: the results are the same bits. */
+ *   reserve_cus  0: the STREAM row kernel keeps one wavefront resident on every SIMD of the device (a workgroup of four
+ *       per compute unit), each holding nearly all of its SIMD's vector registers - until it ends no kernel of another
+ *       stream can start.  n > 0: it occupies n compute units fewer and leaves those wholly free, so that such a kernel
+ *       - the RCCL all-gather of the previous row chunk in a multi-GPU run - can run beside it.  Measured on MI355X: a
+ *       kernel with workgroups of several wavefronts is dispatched only when every shader engine has a free unit, so
+ *       n below the number of shader engines (32 = compute units / 8) changes nothing.  The rows are handed out while
+ *       the kernel runs and solved independently: the results are the same bits for every n. */
 #define ALS_ACCUMULATE_DEFAULT 0
 #define ALS_ACCUMULATE_BF16X3 1
 #define ALS_ACCUMULATE_FP32 2

@@ -601,6 +601,7 @@ struct SweepParams {
     float *partials;
     float *rowdiff;
     int32_t *info;
+    int32_t *stream_next;   // two counters of the stream kernel's launches (chunk items, whole rows): next unclaimed item
     int64_t ldy, ldx;
     int32_t f, chunk_nnz;
     float alpha;
@@ -1004,14 +1005,26 @@ static int32_t half_sweep_impl(const SweepParams &p, int64_t n_rows, int64_t n_i
             // The chunk items of long rows: as streams too once every resident wave gets several of them (their static
             // shares are then even; with few, the one-wave kernel's workgroups, handed out as SIMDs fall free, balance
             // better).  Same partial sums bit for bit either way.
+            // the items of a launch are handed out through a counter that starts behind every wave's two fixed batches
+            // (batches of STREAM_BATCH items; smaller ones when a wave would not get two of those)
+            auto batch_for = [&](const int64_t n, const int64_t n_waves) {
+                return (int)std::max<int64_t>(1, std::min<int64_t>(STREAM_BATCH, n / (2 * n_waves)));
+            };
+            auto start_counter = [&](int32_t *c, const int64_t n_waves, const int batch) {
+                return hipMemsetD32Async((hipDeviceptr_t)c, (int)(2 * n_waves * batch), 1, st);
+            };
+            if (n_items > 0x7fffffffLL - 8 * waves * STREAM_BATCH)
+                return fail(ALS_ERR_UNSUPPORTED, "too many work items for one launch of the stream kernel");
             if (n_chunk_items >= ALS_STREAM_CHUNKS_MIN_PER_WAVE * 4 * (int64_t)cus) {
                 const dim3 grid((unsigned)(waves / STREAM_WG_WAVES)), block(64 * STREAM_WG_WAVES);
+                const int batch = batch_for(n_chunk_items, waves);
+                ALS_HIP_CHECK(start_counter(p.stream_next, waves, batch));
                 if (o.f16) {
-                    if (p.f == 128) hipLaunchKernelGGL((sweep_stream_kernel<true, true, true>), grid, block, 0, st, p, (int64_t)0, n_chunk_items);
-                    else hipLaunchKernelGGL((sweep_stream_kernel<false, true, true>), grid, block, 0, st, p, (int64_t)0, n_chunk_items);
+                    if (p.f == 128) hipLaunchKernelGGL((sweep_stream_kernel<true, true, true>), grid, block, 0, st, p, (int64_t)0, n_chunk_items, batch);
+                    else hipLaunchKernelGGL((sweep_stream_kernel<false, true, true>), grid, block, 0, st, p, (int64_t)0, n_chunk_items, batch);
                 } else {
-                    if (p.f == 128) hipLaunchKernelGGL((sweep_stream_kernel<true, true, false>), grid, block, 0, st, p, (int64_t)0, n_chunk_items);
-                    else hipLaunchKernelGGL((sweep_stream_kernel<false, true, false>), grid, block, 0, st, p, (int64_t)0, n_chunk_items);
+                    if (p.f == 128) hipLaunchKernelGGL((sweep_stream_kernel<true, true, false>), grid, block, 0, st, p, (int64_t)0, n_chunk_items, batch);
+                    else hipLaunchKernelGGL((sweep_stream_kernel<false, true, false>), grid, block, 0, st, p, (int64_t)0, n_chunk_items, batch);
                 }
                 ALS_HIP_CHECK(hipGetLastError());
             } else if (n_chunk_items > 0) {
@@ -1026,13 +1039,16 @@ static int32_t half_sweep_impl(const SweepParams &p, int64_t n_rows, int64_t n_i
                 ALS_HIP_CHECK(hipGetLastError());
             }
             if (n_whole > 0) {
-                const dim3 grid((unsigned)ceil_div(std::min<int64_t>(n_whole, waves), STREAM_WG_WAVES)), block(64 * STREAM_WG_WAVES);
+                const int64_t groups = ceil_div(std::min<int64_t>(n_whole, waves), STREAM_WG_WAVES);
+                const dim3 grid((unsigned)groups), block(64 * STREAM_WG_WAVES);
+                const int batch = batch_for(n_whole, groups * STREAM_WG_WAVES);
+                ALS_HIP_CHECK(start_counter(p.stream_next + 1, groups * STREAM_WG_WAVES, batch));
                 if (o.f16) {
-                    if (p.f == 128) hipLaunchKernelGGL((sweep_stream_kernel<true, false, true>), grid, block, 0, st, p, n_chunk_items, n_whole);
-                    else hipLaunchKernelGGL((sweep_stream_kernel<false, false, true>), grid, block, 0, st, p, n_chunk_items, n_whole);
+                    if (p.f == 128) hipLaunchKernelGGL((sweep_stream_kernel<true, false, true>), grid, block, 0, st, p, n_chunk_items, n_whole, batch);
+                    else hipLaunchKernelGGL((sweep_stream_kernel<false, false, true>), grid, block, 0, st, p, n_chunk_items, n_whole, batch);
                 } else {
-                    if (p.f == 128) hipLaunchKernelGGL((sweep_stream_kernel<true, false, false>), grid, block, 0, st, p, n_chunk_items, n_whole);
-                    else hipLaunchKernelGGL((sweep_stream_kernel<false, false, false>), grid, block, 0, st, p, n_chunk_items, n_whole);
+                    if (p.f == 128) hipLaunchKernelGGL((sweep_stream_kernel<true, false, false>), grid, block, 0, st, p, n_chunk_items, n_whole, batch);
+                    else hipLaunchKernelGGL((sweep_stream_kernel<false, false, false>), grid, block, 0, st, p, n_chunk_items, n_whole, batch);
                 }
                 ALS_HIP_CHECK(hipGetLastError());
             }
@@ -1332,6 +1348,8 @@ int32_t als_half_sweep_tiles_(const int64_t *rowptr, const int32_t *col, const f
     p.partials = (float *)ws; ws += align_up((size_t)n_slots * pq, 256);
     p.rowdiff = (float *)ws; ws += align_up((size_t)n_rows * sizeof(float), 256);
     double *diff_partials = (double *)ws;
+    ws += align_up((size_t)(ceil_div(n_rows, DIFF_BLOCK_ROWS) + 1) * sizeof(double), 256);
+    p.stream_next = (int32_t *)ws;          // in the 256 spare bytes that end the workspace
     p.info = info_out; p.ldy = ldy; p.ldx = ldx; p.f = f; p.chunk_nnz = chunk_nnz; p.alpha = alpha;
     // The library's own choice of the fp16 x 2 accumulate (2^-21 per product against 2^-23) is limited to fixed factors
     // with at least 16 rows per factor: with fewer the Gram is close to singular (at 2 rows per factor and lamb = 0.01
@@ -1388,7 +1406,7 @@ int32_t als_half_sweep_wide_(const int64_t *rowptr, const int32_t *col, const fl
     p.rowdiff = (float *)ws; ws += align_up((size_t)n_rows * sizeof(float), 256);
     double *diff_partials = (double *)ws;
     p.info = info_out; p.ldy = ldy; p.ldx = ldx; p.f = f; p.chunk_nnz = chunk_nnz; p.alpha = alpha;
-    p.cg_steps = cg_steps; p.lamb = lamb; p.rmax = 0.f;
+    p.cg_steps = cg_steps; p.lamb = lamb; p.rmax = 0.f; p.stream_next = nullptr;
     // 16-byte loads: whole vectors inside a row, aligned base, 32-bit row offsets in vector units
     const bool vec = (f % 4 == 0) && (ldy % 4 == 0) && ((uintptr_t)Yopp % 16 == 0) && (n_opp * (ldy / 4) < 0xffffffffLL);
     hipStream_t st = (hipStream_t)stream;

@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--blocks", type=int, default=32)
     ap.add_argument("--threads", type=int, default=256, help="threads per workgroup of the stand-in (64, 128 or 256)")
+    ap.add_argument("--held", type=int, nargs="*", default=[0, 32, 64],
+                    help="second experiment: workgroups of the stand-in that are resident before the sweep starts")
+    ap.add_argument("--hold-passes", type=int, default=8, help="... and how many passes over the buffer they make")
     ap.add_argument("--delay-ms", type=float, default=4.0,
                     help="host-side wait between queueing the sweep and the copy (the sweep takes 20-30 ms)")
     args = ap.parse_args()
@@ -54,15 +57,15 @@ def main():
     ev = lambda: torch.cuda.Event(enable_timing=True)
     import ctypes
     probe = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ubench", "libprobe_copy.so"))
-    probe.probe_copy_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+    probe.probe_copy_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_void_p]
 
-    def copy(kind):
+    def copy(kind, blocks=None, passes=1):
         if kind == "runtime":
             dst.copy_(src)
         else:
-            rc = probe.probe_copy_launch(src.data_ptr(), dst.data_ptr(), src.numel(), args.blocks, args.threads,
-                                         torch.cuda.current_stream(dev).cuda_stream)
+            rc = probe.probe_copy_launch(src.data_ptr(), dst.data_ptr(), src.numel(), blocks or args.blocks, args.threads,
+                                         passes, torch.cuda.current_stream(dev).cuda_stream)
             assert rc == 0, rc
 
     out = {"copy_mb": args.mb, "blocks": args.blocks, "threads": args.threads, "delay_ms": args.delay_ms, "runs": []}
@@ -91,6 +94,31 @@ def main():
                 best = t if best is None or t[1] < best[1] else best      # the first pass warms up
             out["runs"].append({"copy": kind, "short_rows": short, "reserve_cus": res, "sweep_ms": best[0],
                                 "copy_done_after_ms": best[1]})
+            print(json.dumps(out["runs"][-1]), flush=True)
+    # The other order: a kernel of another stream is already resident on `held` compute units when the sweep starts and
+    # stays for several milliseconds (a collective that began first).  The stream kernel's workgroups that find no
+    # unit start late; with rows handed out while the kernel runs they take fewer rows and the sweep loses about the
+    # share of the chip that was held - fixed shares would make it wait for the late workgroups' whole share.
+    for held in args.held:
+        for short in (True, False):
+            best = None
+            for _ in range(args.reps + 1):
+                X = X0.clone()
+                torch.cuda.synchronize()
+                e0, e1, h0, h1 = ev(), ev(), ev(), ev()
+                with torch.cuda.stream(side):
+                    h0.record(side)
+                    if held:
+                        copy("rccl_like", blocks=held, passes=args.hold_passes)
+                    h1.record(side)
+                time.sleep(0.0005)
+                e0.record(main_s)
+                ops.half_sweep(csr, Y, cache, X, wl["alpha"], opts=ops.sweep_opts(), short_rows=short)
+                e1.record(main_s)
+                torch.cuda.synchronize()
+                t = (e0.elapsed_time(e1), h0.elapsed_time(h1))
+                best = t if best is None or t[0] < best[0] else best
+            out["runs"].append({"held_workgroups": held, "short_rows": short, "sweep_ms": best[0], "held_for_ms": best[1]})
             print(json.dumps(out["runs"][-1]), flush=True)
     print(json.dumps(out))
 

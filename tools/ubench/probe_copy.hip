@@ -8,16 +8,18 @@
 #include <cstdint>
 
 __global__ __launch_bounds__(256) void probe_copy_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst,
-                                                        const size_t n16, const int keep_lds) {
+                                                        const size_t n16, const int passes, const int keep_lds) {
     __shared__ uint4 pad[1024];
     asm volatile("v_mov_b32 v127, 0" ::: "v127");      // the kernel is allocated 128 vector registers
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {     // four loads in flight per thread
-        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    for (int pass = 0; pass < passes; ++pass) {             // (several passes: a kernel that stays resident that long)
+        size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        for (; i + 3 * stride < n16; i += 4 * stride) {     // four loads in flight per thread
+            const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+            dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+        }
+        for (; i < n16; i += stride) dst[i] = src[i];
     }
-    for (; i < n16; i += stride) dst[i] = src[i];
     if (keep_lds) {                                     // never taken: keeps the LDS allocation
         pad[threadIdx.x] = src[threadIdx.x];      // (threads <= 256)
         __syncthreads();
@@ -25,8 +27,8 @@ __global__ __launch_bounds__(256) void probe_copy_kernel(const uint4 *__restrict
     }
 }
 
-extern "C" int probe_copy_launch(const void *src, void *dst, size_t bytes, int blocks, int threads, void *stream) {
+extern "C" int probe_copy_launch(const void *src, void *dst, size_t bytes, int blocks, int threads, int passes, void *stream) {
     hipLaunchKernelGGL(probe_copy_kernel, dim3((unsigned)blocks), dim3((unsigned)threads), 0, (hipStream_t)stream, (const uint4 *)src,
-                       (uint4 *)dst, bytes / 16, 0);
+                       (uint4 *)dst, bytes / 16, passes, 0);
     return (int)hipGetLastError();
 }
