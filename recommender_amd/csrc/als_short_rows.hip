@@ -82,6 +82,11 @@ __device__ __forceinline__ void split8_scaled_f16(const f32x4 &a, const f32x4 &b
     }
 }
 
+// block rows from which the solve's tile products run on the bf16 pipe (below: float32 MFMAs); 5 and 7 measured the
+// same as 8 on the 1.25 M x 1 M block (A/B on one box, within +-0.5 %)
+#ifndef SHORT_BF16_SOLVE_FROM
+#define SHORT_BF16_SOLVE_FROM 8
+#endif
 // waves per SIMD the kernel's register budget is sized for
 __host__ __device__ constexpr int short_waves(const int NB) { return NB <= 2 ? 4 : NB <= 4 ? 3 : NB <= 6 ? 2 : 1; }
 
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(64, short_waves(NB)) void short_rows_kernel(const S
         for (int r = 0; r < 4; ++r) T[tile_index(a, a, NB)][r] += (4 * g + r == i) ? 1.f : 0.f;
     float t[NB];
     bool ok;
-    if constexpr (NB >= 8) ok = blocked_solve_bf16<NB>(T, rhs, t, lane);
+    if constexpr (NB >= SHORT_BF16_SOLVE_FROM) ok = blocked_solve_bf16<NB>(T, rhs, t, lane);
     else ok = blocked_solve<NB>(T, rhs, t, lane);
 
     // ---- pass 2: x = sum_e sqrt(w_e) t_e z_e.  The matrix is dead: its registers take the Z rows of ZB slices at a

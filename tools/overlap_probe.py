@@ -8,8 +8,8 @@ collective: user half-sweep of the 1.25 M x 1 M block (f = 128) on the main stre
 side stream submitted `--delay-ms` after the sweep was queued, i.e. while its persistent kernel runs; reported per reserve_cus: the sweep's duration and the time from
 the sweep's start to the copy's end (alone, the copy takes `copy_alone_ms`).  Two stand-ins: the runtime's own copy
 kernel (a handful of registers: it fits into the 40 registers the stream kernel leaves on a SIMD) and
-tools/ubench/probe_copy.hip with the footprint of an RCCL kernel (`--blocks` workgroups of 256 threads, 128 vector
-registers, 16 KB of LDS), built with the hipcc line in that file.
+tools/ubench/probe_copy.hip with the footprint of an RCCL kernel (`--blocks` workgroups of 256 threads, 288 vector
+registers, 16 KB of LDS: one workgroup fills a compute unit, as rcclGenericKernel does), built with the hipcc line in that file.
 
     python tools/overlap_probe.py [--reserve 0 4 8 16 32] [--mb 640] [--blocks 32]
 """
