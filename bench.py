@@ -68,7 +68,11 @@ def parse():
                          "entry-space form (auto: where it pays, see recommender_amd/als.py::short_rows_pay)")
     ap.add_argument("--reserve-cus", type=int, default=None,
                     help="multi-GPU, 64 < f <= 128: compute units the persistent row kernel leaves free for the RCCL "
-                         "exchange that runs beside it (default: the engine's choice, one eighth of them; 0 = none)")
+                         "exchange that runs beside it (default: the engine's choice, 0 = none; see --gap-ticks)")
+    ap.add_argument("--gap-ticks", type=int, default=None,
+                    help="multi-GPU: length of the spin kernel behind the event that holds the next row chunk's sweep back until "
+                         "the exchange of the previous one has been released (default: the engine's 20000; 0 = event only; "
+                         "-1 = no gap at all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="only the headline measurement")
     ap.add_argument("--also-steps", type=int, default=3)
@@ -204,7 +208,7 @@ class Ctx:
 
 
 def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel, steps, warmup, shards=None,
-            short_rows="auto", reserve_cus=None):
+            short_rows="auto", reserve_cus=None, gap_ticks=None):
     """Builds (or reuses) the shards of `workload`, runs warmup + `steps` timed iterations and returns
     (result dict, shards, host init or None).  Every per-row kernel of every half-sweep is bracketed by
     events the library records on the launch stream (als_sweep_opts_t.tap_begin/tap_end)."""
@@ -239,7 +243,8 @@ def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel,
                           chunk_nnz=2048 * (1 if int(wl.get("blocks", world)) == 1 else 4))
     eng = ALSEngine(csr_u, csr_i, X, Y, wl["lamb"], wl["alpha"], ub, ib, group, solver=solver,
                     cg_steps=cg_steps, cg_form=cg_form, short_rows={"auto": "auto", "on": True, "off": False}[short_rows]
-                    if solver != "cg" else False, stream_reserve_cus=reserve_cus)
+                    if solver != "cg" else False, stream_reserve_cus=reserve_cus,
+                    **({} if gap_ticks is None else {"exchange_gap_ticks": gap_ticks}))
     short = dict(eng.short)
     cg = solver == "cg"
     lockstep = cg and (cg_form == "lock_step" or (cg_form == "auto" and f > 128))
@@ -330,6 +335,7 @@ def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel,
     }
     if exposed is not None:
         exposed["stream_reserve_cus"] = eng.stream_reserve_cus
+        exposed["exchange_gap_ticks"] = eng.exchange_gap_ticks
         res["exchange"] = exposed
     if "blocks" in wl:
         res["scaling"] = strong_scaling(workload, f, solver, world, dt / steps * 1e3)
@@ -661,7 +667,7 @@ def main():
         return
     head, shards, (Xh, Yh, wl) = measure(ctx, args.workload, args.factors, args.solver, args.cg_steps, args.cg_form,
                                          args.accumulate, args.row_kernel, args.steps, args.warmup,
-                                         short_rows=args.short_rows, reserve_cus=args.reserve_cus)
+                                         short_rows=args.short_rows, reserve_cus=args.reserve_cus, gap_ticks=args.gap_ticks)
     f = head["f"]
     cg = head["solver"] == "cg"
 
@@ -681,7 +687,7 @@ def main():
             try:
                 r, prev, _ = measure(ctx, wname, ff, solver, cgs if cgs > 0 else args.cg_steps, "auto", args.accumulate, args.row_kernel,
                                      args.also_steps, 1, shards=prev if sh == "prev" else sh, short_rows=args.short_rows,
-                                     reserve_cus=args.reserve_cus)
+                                     reserve_cus=args.reserve_cus, gap_ticks=args.gap_ticks)
                 also.append({"workload": r["workload"], "f": r["f"], "solver": r["solver"], "cg_steps": r["cg_steps"],
                              "steps": r["steps"],
                              "nnz_per_s": r["value"], "ms_per_step": r["ms_per_step"], "launch_ms": r["launch_ms"],

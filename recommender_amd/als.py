@@ -128,7 +128,7 @@ _PADDED_RECV = {}      # (device, dtype, world, trailing shape) -> (receive, sen
 UNEVEN_FORMS = ("padded", "list")
 
 
-def _all_gather_row_blocks(T, starts, sizes, rank, group, uneven="padded"):
+def _all_gather_row_blocks(T, starts, sizes, rank, group, uneven="padded", before=None):
     """All-gather of one row block per rank of the replicated T, in place: rank r owns
     T[starts[r] : starts[r] + sizes[r]] and every rank ends up with all of them:
 
@@ -139,7 +139,9 @@ def _all_gather_row_blocks(T, starts, sizes, rank, group, uneven="padded"):
         block is copied to its place: a second copy of the gathered rows and one more pass over them);
         uneven="list": all_gather into the views, which torch issues as one broadcast per rank inside one RCCL
         group - every receive lands in place, no staging buffer, no copy pass;
-      * other backends (gloo in tests): one broadcast per rank of host copies - they get host tensors (_host_staged)."""
+      * other backends (gloo in tests): one broadcast per rank of host copies - they get host tensors (_host_staged).
+    before: called immediately in front of the collective call, behind any packing of this rank's
+    block - the overlapped sweep records there the event its main stream waits for (ALSEngine._sweep_users)."""
     if uneven not in UNEVEN_FORMS:
         raise ValueError("uneven must be one of %s" % (UNEVEN_FORMS,))
     world = len(sizes)
@@ -149,6 +151,8 @@ def _all_gather_row_blocks(T, starts, sizes, rank, group, uneven="padded"):
     equal = len(set(sizes)) == 1
     if _host_staged(T, group) or not T.is_cuda:
         host = T.is_cuda
+        if before is not None:      # (no collective kernel to make room for; called so that rehearsals walk the same code)
+            before()
         for r in range(world):
             if not sizes[r]:
                 continue
@@ -162,15 +166,19 @@ def _all_gather_row_blocks(T, starts, sizes, rank, group, uneven="padded"):
                 blk.copy_(buf)
         return
     if equal and T.is_contiguous() and all(starts[r] == r * sizes[0] for r in range(world)) and sizes[0] * world == T.shape[0]:
+        if before is not None:
+            before()
         torch.distributed.all_gather_into_tensor(T, mine, group=group)      # blocks tile T: no staging at all
         return
     if equal or uneven == "list":
+        if before is not None:
+            before()
         torch.distributed.all_gather([T[starts[r]: starts[r] + sizes[r]] for r in range(world)], mine, group=group)
         return
-    _all_gather_padded(T, starts, sizes, rank, group)
+    _all_gather_padded(T, starts, sizes, rank, group, before)
 
 
-def _all_gather_padded(T, starts, sizes, rank, group):
+def _all_gather_padded(T, starts, sizes, rank, group, before=None):
     """Row blocks of different sizes, padded to the longest: ONE all_gather_into_tensor through a receive and a send
     buffer kept per (device, dtype, world, row shape) - sized for the longest block seen so far, so the chunks of an
     overlapped sweep share one pair -, then every other rank's block is copied to its place in T."""
@@ -185,6 +193,8 @@ def _all_gather_padded(T, starts, sizes, rank, group):
     recv = bufs[0][: world * cap].view((world, cap) + tail)
     send = bufs[1][:cap]
     send[: sizes[rank]] = T[starts[rank]: starts[rank] + sizes[rank]]
+    if before is not None:
+        before()
     torch.distributed.all_gather_into_tensor(recv.view((world * cap,) + tail), send, group=group)
     for r in range(world):
         if r != rank and sizes[r]:
@@ -222,7 +232,7 @@ class ALSEngine:
 
     def __init__(self, csr_users, csr_items, X, Y, lamb, alpha, user_bounds=None, item_bounds=None, group=None,
                  backend=ops, overlap_chunks=None, solver="auto", cg_steps=None, cg_form="auto", short_rows="auto",
-                 uneven_exchange="padded", stream_reserve_cus=None):
+                 uneven_exchange="padded", stream_reserve_cus=None, exchange_gap_ticks=20000):
         self.group = group
         if uneven_exchange not in UNEVEN_FORMS:
             raise ValueError("uneven_exchange must be one of %s" % (UNEVEN_FORMS,))
@@ -282,18 +292,24 @@ class ALSEngine:
         self.overlap_chunks = max(1, int(overlap_chunks))      # the same on every rank
         self._user_parts = None
         self._side = None
-        # The persistent row kernel of 64 < f <= 128 holds every SIMD's registers until it ends: a kernel of another
-        # stream that becomes ready meanwhile - the RCCL exchange of the previous row chunk - starts only behind it, and
-        # the overlap the chunks exist for shrinks to the other kernels' share of a chunk.  In a chunked multi-GPU sweep
-        # it therefore leaves compute units free (als_sweep_opts_t.reserve_cus; the results do not depend on it) in
-        # every chunk that has an exchange running beside it, i.e. all but the first.  How many: measured on one
-        # MI355X (tools/overlap_probe.py), a kernel with workgroups of several waves is dispatched only when EVERY
-        # shader engine has a wholly free compute unit - with 32 engines of 8 units, 31 free units are as good as none,
-        # 32 let a 256-thread kernel run at once - hence one eighth of the units.
+        # Overlap of the exchange of row chunk c with the sweep of chunk c + 1, as measured on one MI355X with a stand-in
+        # of RCCL's kernel (tools/overlap_probe.py; its workgroups of 256 threads and 261-280 registers need a wholly
+        # free compute unit each):
+        #  * the collective and the next sweep become runnable at the same instant, when the chip drains - and the sweep's
+        #    tens of thousands of small workgroups take every unit first, after which the collective finds no free
+        #    unit until that sweep has ENDED (f = 64: done 10.8 ms after the event instead of 4.5).  Hence the gap: the
+        #    main stream waits for an event the side stream records immediately in front of the collective call, plus a
+        #    few microseconds of a one-wave spin kernel - the collective's workgroups are resident before the sweep
+        #    starts, and the sweep runs on the units that are left;
+        #  * the persistent row kernel of 64 < f <= 128 hands its rows out while it runs, so the units the collective
+        #    holds cost their share of the chip and no more;
+        #  * stream_reserve_cus > 0 makes that kernel leave units free in the chunks that have an exchange beside them
+        #    (als_sweep_opts_t.reserve_cus) - the remedy for a collective that becomes runnable while the kernel is
+        #    already resident.  With the gap it is not needed (measured: no gain, -12 % on the kernel), so 0.
         if stream_reserve_cus is None:
-            rccl = self.world > 1 and self.overlap_chunks > 1 and X.is_cuda and not _host_staged(X, group)
-            stream_reserve_cus = torch.cuda.get_device_properties(X.device).multi_processor_count // 8 if rccl else 0
+            stream_reserve_cus = 0
         self.stream_reserve_cus = int(stream_reserve_cus)
+        self.exchange_gap_ticks = int(exchange_gap_ticks)      # spin kernel of the gap, in clock ticks; 0: event only; < 0: no gap
         # benchmarks set this to {"x_wait": [], "y_gather": []}: per step, event pairs around the main stream's wait for
         # the user exchange still in flight when the user sweep has been queued, and around the item exchange
         self.exchange_taps = None
@@ -375,10 +391,18 @@ class ALSEngine:
                 cuts = _chunk_cuts(self.user_bounds[r + 1] - self.user_bounds[r], self.overlap_chunks)
                 starts.append(self.user_bounds[r] + cuts[c]); sizes.append(cuts[c + 1] - cuts[c])
             if on_gpu:
-                self._side.wait_stream(torch.cuda.current_stream(self.X.device))
+                main = torch.cuda.current_stream(self.X.device)
+                self._side.wait_stream(main)
+                released = []
                 with torch.cuda.stream(self._side):
-                    _all_gather_row_blocks(self.X, starts, sizes, self.rank, self.group, self.uneven_exchange)
+                    _all_gather_row_blocks(self.X, starts, sizes, self.rank, self.group, self.uneven_exchange,
+                                           before=lambda: released.append(self._side.record_event()))
                     done.append(self._side.record_event())
+                if released and c + 1 < len(parts) and self.exchange_gap_ticks >= 0:
+                    # the gap: the next chunk's sweep starts once the collective has been released, and a moment later
+                    main.wait_event(released[0])
+                    if self.exchange_gap_ticks > 0 and hasattr(torch.cuda, "_sleep"):
+                        torch.cuda._sleep(self.exchange_gap_ticks)
             else:
                 _all_gather_row_blocks(self.X, starts, sizes, self.rank, self.group, self.uneven_exchange)
         tap = self._tap_begin("x_wait") if self.world > 1 else None

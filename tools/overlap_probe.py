@@ -31,6 +31,14 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--blocks", type=int, default=32)
     ap.add_argument("--threads", type=int, default=256, help="threads per workgroup of the stand-in (64, 128 or 256)")
+    ap.add_argument("--factors", type=int, default=128,
+                    help="factor count; at f <= 64 the sweep is the one-wave-per-row kernel with three waves per SIMD")
+    ap.add_argument("--high-priority", action="store_true", help="the side stream is created with high priority")
+    ap.add_argument("--gap-event", action="store_true",
+                    help="third experiment: the main stream waits for an event the side stream records in front of its copy")
+    ap.add_argument("--gap-cycles", type=int, default=0,
+                    help="third experiment: a spin kernel of that many clock ticks on the main stream in front of the second sweep")
+    ap.add_argument("--pattern-passes", type=int, default=4, help="third experiment: passes of the stand-in (its duration)")
     ap.add_argument("--held", type=int, nargs="*", default=[0, 32, 64],
                     help="second experiment: workgroups of the stand-in that are resident before the sweep starts")
     ap.add_argument("--hold-passes", type=int, default=8, help="... and how many passes over the buffer they make")
@@ -40,7 +48,7 @@ def main():
     from recommender_amd import data, ops
     dev = torch.device("cuda", 0)
     wl = data.WORKLOADS["c3_shard_syn"]
-    nb, M, f = wl["n_users"], wl["n_items"], wl["f"]
+    nb, M, f = wl["n_users"], wl["n_items"], args.factors
     keys, r = data.synth_pairs(nb, M, wl["nnz"], seed=1234, device=dev, item_seed=1234)
     U = data.csr_from_sorted_keys(keys, r, nb, M)
     del keys, r
@@ -49,10 +57,12 @@ def main():
     X0 = torch.randn((nb, f), generator=g, device=dev) / f ** 0.5
     Y = torch.randn((M, f), generator=g, device=dev) / f ** 0.5
     cache = ops.gram(Y, wl["lamb"])
-    ops.whiten(Y, cache)
+    can_short = ops.short_rows_max_entries(f) > 0
+    if can_short:
+        ops.whiten(Y, cache)
     src = torch.empty(args.mb << 20, dtype=torch.uint8, device=dev)
     dst = torch.empty_like(src)
-    side = torch.cuda.Stream(device=dev)
+    side = torch.cuda.Stream(device=dev, priority=-1 if args.high_priority else 0)
     main_s = torch.cuda.current_stream(dev)
     ev = lambda: torch.cuda.Event(enable_timing=True)
     import ctypes
@@ -68,13 +78,15 @@ def main():
                                          passes, torch.cuda.current_stream(dev).cuda_stream)
             assert rc == 0, rc
 
-    out = {"copy_mb": args.mb, "blocks": args.blocks, "threads": args.threads, "delay_ms": args.delay_ms, "runs": []}
+    out = {"f": f, "high_priority_side_stream": args.high_priority, "copy_mb": args.mb, "blocks": args.blocks, "threads": args.threads, "delay_ms": args.delay_ms, "runs": []}
     for kind in ("runtime", "rccl_like"):
         copy(kind); torch.cuda.synchronize()
         a, b = ev(), ev()
         a.record(); copy(kind); b.record(); torch.cuda.synchronize()
         out["copy_alone_ms_" + kind] = a.elapsed_time(b)
     for kind, short in (("runtime", True), ("rccl_like", True), ("rccl_like", False)):
+        if short and not (can_short and f > 64):
+            continue
         for res in args.reserve:
             best = None
             for _ in range(args.reps + 1):
@@ -101,6 +113,8 @@ def main():
     # share of the chip that was held - fixed shares would make it wait for the late workgroups' whole share.
     for held in args.held:
         for short in (True, False):
+            if short and not (can_short and f > 64):
+                continue
             best = None
             for _ in range(args.reps + 1):
                 X = X0.clone()
@@ -119,6 +133,39 @@ def main():
                 t = (e0.elapsed_time(e1), h0.elapsed_time(h1))
                 best = t if best is None or t[0] < best[0] else best
             out["runs"].append({"held_workgroups": held, "short_rows": short, "sweep_ms": best[0], "held_for_ms": best[1]})
+            print(json.dumps(out["runs"][-1]), flush=True)
+    # The engine's own pattern: everything is queued ahead of time - sweep of chunk c, an event, sweep of chunk c + 1
+    # on the main stream; on the side stream the exchange of chunk c, which waits for that event.  Exchange and next
+    # sweep become runnable at the same instant, at a kernel boundary, when the chip drains.
+    for res in args.reserve:
+        for short in (True, False):
+            if short and not (can_short and f > 64):
+                continue
+            best = None
+            for _ in range(args.reps + 1):
+                X = X0.clone()
+                torch.cuda.synchronize()
+                e0, e1, e2, c1 = ev(), ev(), ev(), ev()
+                e0.record(main_s)
+                ops.half_sweep(csr, Y, cache, X, wl["alpha"], opts=ops.sweep_opts(), short_rows=short)
+                e1.record(main_s)
+                side.wait_event(e1)
+                with torch.cuda.stream(side):
+                    released = side.record_event() if args.gap_event else None
+                    copy("rccl_like", passes=args.pattern_passes)
+                    c1.record(side)
+                if released is not None:
+                    main_s.wait_event(released)             # main stream: goes on when the side stream has been released
+                if args.gap_cycles:
+                    torch.cuda._sleep(args.gap_cycles)      # main stream: a one-wave kernel that spins that long
+                ops.half_sweep(csr, Y, cache, X, wl["alpha"], opts=ops.sweep_opts(reserve_cus=res), short_rows=short)
+                e2.record(main_s)
+                torch.cuda.synchronize()
+                t = (e0.elapsed_time(e1), e1.elapsed_time(e2), e1.elapsed_time(c1))
+                best = t if best is None or t[2] < best[2] else best
+            out["runs"].append({"pattern": "sweep, event, sweep || exchange after the event", "short_rows": short,
+                                "reserve_cus_second_sweep": res, "gap_cycles": args.gap_cycles, "gap_event": args.gap_event, "first_sweep_ms": best[0], "second_sweep_ms": best[1],
+                                "exchange_done_after_event_ms": best[2]})
             print(json.dumps(out["runs"][-1]), flush=True)
     print(json.dumps(out))
 
