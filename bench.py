@@ -259,7 +259,7 @@ def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel,
     eng.sweep_opts = lambda which: ops.sweep_opts(**base_opts)
     for _ in range(warmup):
         eng.step()
-    launches_per_step = (len(eng._parts()) if world > 1 else 1) + 1
+    launches_per_step = eng.launches_per_step()
     pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * launches_per_step * steps)]
     for e in pool:
         e.record()          # materialise the handles

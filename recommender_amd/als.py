@@ -231,7 +231,7 @@ class ALSEngine:
     """
 
     def __init__(self, csr_users, csr_items, X, Y, lamb, alpha, user_bounds=None, item_bounds=None, group=None,
-                 backend=ops, overlap_chunks=None, solver="auto", cg_steps=None, cg_form="auto", short_rows="auto",
+                 backend=ops, overlap_chunks=None, item_overlap_chunks=None, solver="auto", cg_steps=None, cg_form="auto", short_rows="auto",
                  uneven_exchange="padded", stream_reserve_cus=None, exchange_gap_ticks=20000):
         self.group = group
         if uneven_exchange not in UNEVEN_FORMS:
@@ -290,7 +290,12 @@ class ALSEngine:
         if overlap_chunks is None:
             overlap_chunks = 4 if self.world > 1 else 1
         self.overlap_chunks = max(1, int(overlap_chunks))      # the same on every rank
-        self._user_parts = None
+        # the item sweep likewise, where the item factor is large enough for its exchange to matter (16 MB a rank)
+        if item_overlap_chunks is None:
+            big = self.n_items * self.f * 4 >= self.world * (16 << 20)
+            item_overlap_chunks = 4 if (self.world > 1 and big) else 1
+        self.item_overlap_chunks = max(1, int(item_overlap_chunks))
+        self._parts_cache = {}
         self._side = None
         # Overlap of the exchange of row chunk c with the sweep of chunk c + 1, as measured on one MI355X with a stand-in
         # of RCCL's kernel (tools/overlap_probe.py; its workgroups of 256 threads and 261-280 registers need a wholly
@@ -349,38 +354,52 @@ class ALSEngine:
         for c in csrs:
             c.max_rating = m
 
-    def _parts(self):
-        """[(row0, row1, csr chunk or None if empty, |delta| buffer)], chunk c of this rank's user shard."""
-        if self._user_parts is None:
-            n = self.csr_users.shape[0]
-            if self.overlap_chunks == 1:
-                self._user_parts = [(0, n, self.csr_users if n else None, self._dX)]
-            else:
-                cuts = _chunk_cuts(n, self.overlap_chunks)
-                self._user_parts = [
-                    (cuts[c], cuts[c + 1],
-                     self.csr_users.row_range(cuts[c], cuts[c + 1]) if cuts[c + 1] > cuts[c] else None,
-                     torch.zeros(1, dtype=torch.float64, device=self.X.device))
-                    for c in range(self.overlap_chunks)]
-        return self._user_parts
+    def _side_of(self, which):
+        """(csr shard, own factor, fixed factor, its cache, shard bounds, chunks, |delta| buffer, rows of the whole factor)"""
+        if which == "users":
+            return (self.csr_users, self.X, self.Y, self.cache_Y, self.user_bounds, self.overlap_chunks, self._dX, self.n_users)
+        return (self.csr_items, self.Y, self.X, self.cache_X, self.item_bounds, self.item_overlap_chunks, self._dY, self.n_items)
 
-    def _sweep_users(self):
-        u0 = self.user_bounds[self.rank]
-        parts = self._parts()
-        chunked = self.world > 1 and self.overlap_chunks > 1
-        on_gpu = self.X.is_cuda
+    def _parts(self, which="users"):
+        """[(row0, row1, csr chunk or None if empty, |delta| buffer)], chunk c of this rank's user (item) shard."""
+        if which not in self._parts_cache:
+            csr, own, _, _, _, chunks, dbuf, _ = self._side_of(which)
+            n = csr.shape[0]
+            if chunks == 1:
+                self._parts_cache[which] = [(0, n, csr if n else None, dbuf)]
+            else:
+                cuts = _chunk_cuts(n, chunks)
+                self._parts_cache[which] = [
+                    (cuts[c], cuts[c + 1], csr.row_range(cuts[c], cuts[c + 1]) if cuts[c + 1] > cuts[c] else None,
+                     torch.zeros(1, dtype=torch.float64, device=own.device))
+                    for c in range(chunks)]
+        return self._parts_cache[which]
+
+    def launches_per_step(self):
+        """Half-sweep calls of one step (benchmarks size their event pools by it)."""
+        return len(self._parts("users")) + len(self._parts("items"))
+
+    def _sweep_side(self, which):
+        """The half-sweep over this rank's user (item) shard and the exchange of the solved rows.  With several ranks
+        and `chunks` > 1 the shard is swept as row chunks and the all-gather of chunk c runs on a side stream beside
+        the sweep of chunk c + 1 (the gap: see __init__); the main stream waits for the exchanges at the end."""
+        csr_all, own, fixed, cache, bounds, chunks, dsum, n_all = self._side_of(which)
+        r0_shard = bounds[self.rank]
+        parts = self._parts(which)
+        chunked = self.world > 1 and chunks > 1
+        on_gpu = own.is_cuda
         if chunked and on_gpu and self._side is None:
-            self._side = torch.cuda.Stream(device=self.X.device)
+            self._side = torch.cuda.Stream(device=own.device)
         done = []
         for c, (r0, r1, csr, dbuf) in enumerate(parts):
             if csr is not None:
-                opts = self.sweep_opts("users") if self.sweep_opts else None
+                opts = self.sweep_opts(which) if self.sweep_opts else None
                 if chunked and c > 0 and self.stream_reserve_cus and self.backend is ops:
                     if opts is None:
                         opts = ops.sweep_opts()
                     opts.reserve_cus = self.stream_reserve_cus
-                run_als_epoch(csr, self.X[u0 + r0:u0 + r1], self.Y, self.cache_Y, self.alpha, dbuf, self.info,
-                              self.backend, self.cg_steps, self.cg_form, opts, self.short["users"])
+                run_als_epoch(csr, own[r0_shard + r0:r0_shard + r1], fixed, cache, self.alpha, dbuf, self.info,
+                              self.backend, self.cg_steps, self.cg_form, opts, self.short[which])
             else:
                 dbuf.zero_()
             if not chunked:
@@ -388,14 +407,14 @@ class ALSEngine:
             # chunk c of every rank: rows [bounds[r] + cuts_r[c], bounds[r] + cuts_r[c+1])
             starts, sizes = [], []
             for r in range(self.world):
-                cuts = _chunk_cuts(self.user_bounds[r + 1] - self.user_bounds[r], self.overlap_chunks)
-                starts.append(self.user_bounds[r] + cuts[c]); sizes.append(cuts[c + 1] - cuts[c])
+                cuts = _chunk_cuts(bounds[r + 1] - bounds[r], chunks)
+                starts.append(bounds[r] + cuts[c]); sizes.append(cuts[c + 1] - cuts[c])
             if on_gpu:
-                main = torch.cuda.current_stream(self.X.device)
+                main = torch.cuda.current_stream(own.device)
                 self._side.wait_stream(main)
                 released = []
                 with torch.cuda.stream(self._side):
-                    _all_gather_row_blocks(self.X, starts, sizes, self.rank, self.group, self.uneven_exchange,
+                    _all_gather_row_blocks(own, starts, sizes, self.rank, self.group, self.uneven_exchange,
                                            before=lambda: released.append(self._side.record_event()))
                     done.append(self._side.record_event())
                 if released and c + 1 < len(parts) and self.exchange_gap_ticks >= 0:
@@ -404,15 +423,18 @@ class ALSEngine:
                     if self.exchange_gap_ticks > 0 and hasattr(torch.cuda, "_sleep"):
                         torch.cuda._sleep(self.exchange_gap_ticks)
             else:
-                _all_gather_row_blocks(self.X, starts, sizes, self.rank, self.group, self.uneven_exchange)
-        tap = self._tap_begin("x_wait") if self.world > 1 else None
+                _all_gather_row_blocks(own, starts, sizes, self.rank, self.group, self.uneven_exchange)
+        tap = self._tap_begin("x_wait" if which == "users" else "y_gather") if self.world > 1 else None
         for ev in done:
-            torch.cuda.current_stream(self.X.device).wait_event(ev)
+            torch.cuda.current_stream(own.device).wait_event(ev)
         if len(parts) > 1:
-            torch.sum(torch.cat([p[3] for p in parts]), 0, keepdim=True, out=self._dX)
+            torch.sum(torch.cat([p[3] for p in parts]), 0, keepdim=True, out=dsum)
         if self.world > 1 and not chunked:
-            _all_gather_rows(self.X[: self.n_users], self.user_bounds, self.rank, self.group, self.uneven_exchange)
+            _all_gather_rows(own[:n_all], bounds, self.rank, self.group, self.uneven_exchange)
         self._tap_end(tap)
+
+    def _sweep_users(self):
+        self._sweep_side("users")
 
     def _tap_begin(self, which):
         if self.exchange_taps is None or not self.X.is_cuda:
@@ -428,7 +450,6 @@ class ALSEngine:
 
     # one ALS iteration = X half-sweep + Y half-sweep, Gram refreshes included
     def step(self):
-        i0, i1 = self.item_bounds[self.rank], self.item_bounds[self.rank + 1]
         als_update_cache(self.Y, self.lamb, self.cache_Y, self.group, self.backend)
         if self.short["users"]:
             self.backend.whiten(self.Y, self.cache_Y, info=self.info)
@@ -436,14 +457,7 @@ class ALSEngine:
         als_update_cache(self.X, self.lamb, self.cache_X, self.group, self.backend)
         if self.short["items"]:
             self.backend.whiten(self.X, self.cache_X, info=self.info)
-        if i1 > i0:
-            run_als_epoch(self.csr_items, self.Y[i0:i1], self.X, self.cache_X, self.alpha, self._dY, self.info,
-                          self.backend, self.cg_steps, self.cg_form, self.sweep_opts("items") if self.sweep_opts else None,
-                          self.short["items"])
-        if self.world > 1:
-            tap = self._tap_begin("y_gather")
-            _all_gather_rows(self.Y[: self.n_items], self.item_bounds, self.rank, self.group, self.uneven_exchange)
-            self._tap_end(tap)
+        self._sweep_side("items")
 
     def last_delta(self):
         """mean|dX| + mean|dY| of the last step, as ALSRef.train's trace (ALS.py:136-139).

@@ -56,7 +56,8 @@ def _run(rank, world, port, N, M, f, balance, out_dir):
     cu = shard(ptr, ind, dat, ub[rank], ub[rank + 1], M)
     ci = shard(tptr, tind, tdat, ib[rank], ib[rank + 1], N)
     X = torch.from_numpy(X0.copy()); Y = torch.from_numpy(Y0.copy())
-    eng = ALSEngine(cu, ci, X, Y, 0.05, 3.0, ub, ib, group, backend=ob)
+    # (the item sweep in overlapped row chunks too, as the engine does by itself for large item factors)
+    eng = ALSEngine(cu, ci, X, Y, 0.05, 3.0, ub, ib, group, backend=ob, item_overlap_chunks=3 if world > 1 else None)
     trace = eng.fit(2)
     np.savez(os.path.join(out_dir, "w%d_r%d_%s.npz" % (world, rank, balance)), X=X.numpy(), Y=Y.numpy(), trace=trace)
     if world > 1:
