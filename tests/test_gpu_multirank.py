@@ -44,7 +44,9 @@ def _worker(rank, world, port, N, M, f, balance, out_dir):
     ci = shard(Ut, int(ib[rank]), int(ib[rank + 1]), N)
     X0, Y0 = init_factors(N, M, f, "tf")
     X = torch.from_numpy(X0.astype(np.float32)).to(dev); Y = torch.from_numpy(Y0.astype(np.float32)).to(dev)
-    eng = ALSEngine(cu, ci, X, Y, 0.01, 40.0, [int(b) for b in ub], [int(b) for b in ib], group)
+    # (item sweep in overlapped row chunks as well: what the engine does by itself for large item factors)
+    eng = ALSEngine(cu, ci, X, Y, 0.01, 40.0, [int(b) for b in ub], [int(b) for b in ib], group,
+                    item_overlap_chunks=2 if world > 1 else None)
     trace = eng.fit(2)
     torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, "w%d_r%d_%s.npz" % (world, rank, balance)), X=X.cpu().numpy(), Y=Y.cpu().numpy(),
