@@ -73,6 +73,8 @@ def parse():
                     help="multi-GPU: length of the spin kernel behind the event that holds the next row chunk's sweep back until "
                          "the exchange of the previous one has been released (default: the engine's 20000; 0 = event only; "
                          "-1 = no gap at all)")
+    ap.add_argument("--tap-every", type=int, default=1,
+                    help="the per-row kernels of every n-th timed step are bracketed by events (launch durations of the roofline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="only the headline measurement")
     ap.add_argument("--also-steps", type=int, default=3)
@@ -208,7 +210,7 @@ class Ctx:
 
 
 def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel, steps, warmup, shards=None,
-            short_rows="auto", reserve_cus=None, gap_ticks=None):
+            short_rows="auto", reserve_cus=None, gap_ticks=None, tap_every=1):
     """Builds (or reuses) the shards of `workload`, runs warmup + `steps` timed iterations and returns
     (result dict, shards, host init or None).  Every per-row kernel of every half-sweep is bracketed by
     events the library records on the launch stream (als_sweep_opts_t.tap_begin/tap_end)."""
@@ -266,7 +268,14 @@ def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel,
     sync()
     taps = {"users": [], "items": []}
 
+    # Event records cost the stream a moment each (four per step; measured: 0.4 % of the 2 ms step of the 25 M-entry
+    # matrix); --tap-every n taps only every n-th step of the timed region
+    state = {"step": 0}
+    tapped_steps = [s for s in range(steps) if s % tap_every == 0]
+
     def tapped(which):
+        if state["step"] % tap_every:
+            return ops.sweep_opts(**base_opts)
         e0, e1 = pool.pop(), pool.pop()
         taps[which].append((e0, e1))
         return ops.sweep_opts(tap=(e0, e1), **base_opts)
@@ -276,7 +285,8 @@ def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel,
         eng.exchange_taps = {"x_wait": [], "y_gather": []}
     sync()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for s_i in range(steps):
+        state["step"] = s_i
         eng.step()
     sync()
     dt = time.perf_counter() - t0
@@ -301,8 +311,8 @@ def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel,
     # dominant kernels: the per-row kernels of a half-sweep (gather/accumulate + solve, the long rows' combine
     # and solve); algorithmic bytes per half-sweep = nnz*(4 col + 4 val + 4f gathered row) + n_rows*(8 rowptr
     # + 4f written row)
-    ku = sum(e0.elapsed_time(e1) for e0, e1 in taps["users"]) / steps
-    ki = sum(e0.elapsed_time(e1) for e0, e1 in taps["items"]) / steps
+    ku = sum(e0.elapsed_time(e1) for e0, e1 in taps["users"]) / len(tapped_steps)
+    ki = sum(e0.elapsed_time(e1) for e0, e1 in taps["items"]) / len(tapped_steps)
     if lockstep:
         # per half-sweep: cg_steps+1 gather passes over the entries, plus the per-row vectors each pass
         # reads and writes (x, r, p, z and the GEMM's operand and result)
@@ -328,7 +338,7 @@ def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel,
                                   % row_kernel if f > 64 and row_kernel != "wave" and accumulate != "fp32" else
                                   "sweep_items_kernel, row_kernel=%s" % row_kernel,
                                   "CG on the formed matrix" if cg else "solve")),
-        "achieved": achieved, "launch_ms": {"user_sweep": ku, "item_sweep": ki},
+        "achieved": achieved, "launch_ms": {"user_sweep": ku, "item_sweep": ki}, "tapped_steps": len(tapped_steps),
         "bytes_per_launch": (bytes_u + bytes_i) / 2,
         "user_rows": csr_u.shape[0], "item_rows": csr_i.shape[0],
         "short_rows": short_rows_note(short, csr_u, csr_i, f),
@@ -667,7 +677,8 @@ def main():
         return
     head, shards, (Xh, Yh, wl) = measure(ctx, args.workload, args.factors, args.solver, args.cg_steps, args.cg_form,
                                          args.accumulate, args.row_kernel, args.steps, args.warmup,
-                                         short_rows=args.short_rows, reserve_cus=args.reserve_cus, gap_ticks=args.gap_ticks)
+                                         short_rows=args.short_rows, reserve_cus=args.reserve_cus, gap_ticks=args.gap_ticks,
+                                         tap_every=max(1, args.tap_every))
     f = head["f"]
     cg = head["solver"] == "cg"
 
