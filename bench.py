@@ -732,6 +732,16 @@ def main():
                     also.append({"workload": "c3_rank_syn", "solver": solver, "error": repr(exc)})
             del state
             torch.cuda.empty_cache()
+            # and the weak-scaled headline matrix as one of its eight ranks runs it (f=64: its user block, its 7 380
+            # items over all 1.3 M users)
+            try:
+                r, state = measure_rank_share(ctx, "c2_rank_syn", "cholesky", None, args.accumulate, args.row_kernel,
+                                              max(args.also_steps, 5), 2, None, short_rows=args.short_rows)
+                also.append(r)
+            except Exception as exc:
+                also.append({"workload": "c2_rank_syn", "solver": "cholesky", "error": repr(exc)})
+            del state
+            torch.cuda.empty_cache()
 
     extra = {}
     if not args.no_also and world == 1 and args.workload == "c2_ml25m_syn" and not args.factors:

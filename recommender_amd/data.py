@@ -106,6 +106,9 @@ WORKLOADS = {
     # what one rank of the eight-GPU run of that matrix executes: its 1.25 M users over all 1 M items, and its
     # 125 000 items over all 10 M users (item rows eight times longer, the whole 5 GB user table gathered from)
     "c3_rank_syn": dict(n_users=1250000, n_items=1000000, nnz=125000000, f=128, lamb=0.01, alpha=40.0, of_world=8),
+    # the same for the weak-scaled 25 M-entry matrix (8 user blocks of 162 541 over the same 59 047 items, f=64): a rank's
+    # user block, and its 7 380 items over all 1.3 M users (rows of 3 400 entries on average, one wavefront each)
+    "c2_rank_syn": dict(n_users=162541, n_items=59047, nnz=25000095, f=64, lamb=0.01, alpha=40.0, of_world=8),
     # one GPU's eighth of the 50 M x 5 M, 4 B-entry matrix (f=256, conjugate-gradient solver)
     "c4_shard_syn": dict(n_users=6250000, n_items=5000000, nnz=500000000, f=256, lamb=0.01, alpha=40.0, iters=15,
                          init="device", solver="cg"),
