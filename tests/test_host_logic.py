@@ -23,6 +23,32 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib.als_abi_version() >= 1
 
 
+def test_option_struct_is_the_same_in_header_binding_and_guide():
+    """als_sweep_opts_t: the header's fields, the ctypes mirror of recommender_amd/_lib.py and the one printed in the
+    integration guide agree in names, order and C types, and both bindings state the library's ABI version - a field
+    added to one of them only would be read as garbage by the library."""
+    from recommender_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "als_hip.h")).read()
+    body = re.search(r"typedef struct \{(.*?)\} als_sweep_opts_t;", hdr, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = " ".join(decl.split())
+        if decl:
+            name = re.search(r"(\w+)$", decl).group(1)
+            ctype = decl[: -len(name)].strip()
+            fields.append((name, ctypes.c_void_p if "*" in ctype else {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64,
+                                                                      "float": ctypes.c_float}[ctype]))
+    assert fields == list(_lib.SweepOpts._fields_)
+    assert _lib.lib.als_abi_version() == _lib.ABI_VERSION
+    guide = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = next(b for b in re.findall(r"```python\n(.*?)```", guide, flags=re.S) if "class SweepOpts" in b)
+    names = re.findall(r'\("(\w+)", (\w+)\)', re.search(r"_fields_ = \[(.*?)\]", stub, flags=re.S).group(1))
+    short = {"i32": ctypes.c_int32, "i64": ctypes.c_int64, "f32": ctypes.c_float, "vp": ctypes.c_void_p}
+    assert [(n, short[t]) for n, t in names] == fields
+    assert "als_abi_version() == %d" % _lib.ABI_VERSION in stub
+
+
 def test_error_strings_and_argument_checks_without_gpu():
     from recommender_amd._lib import lib
     n = ctypes.c_int64()
