@@ -73,6 +73,9 @@ def parse():
                     help="multi-GPU: length of the spin kernel behind the event that holds the next row chunk's sweep back until "
                          "the exchange of the previous one has been released (default: the engine's 20000; 0 = event only; "
                          "-1 = no gap at all)")
+    ap.add_argument("--overlap-chunks", type=int, default=None,
+                    help="row chunks of the user sweep whose exchange runs beside the next chunk's sweep (default: 4 with "
+                         "several GPUs, 1 on one; on one GPU a value > 1 measures what the chunking itself costs)")
     ap.add_argument("--tap-every", type=int, default=1,
                     help="the per-row kernels of every n-th timed step are bracketed by events (launch durations of the roofline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -210,7 +213,7 @@ class Ctx:
 
 
 def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel, steps, warmup, shards=None,
-            short_rows="auto", reserve_cus=None, gap_ticks=None, tap_every=1):
+            short_rows="auto", reserve_cus=None, gap_ticks=None, tap_every=1, overlap_chunks=None):
     """Builds (or reuses) the shards of `workload`, runs warmup + `steps` timed iterations and returns
     (result dict, shards, host init or None).  Every per-row kernel of every half-sweep is bracketed by
     events the library records on the launch stream (als_sweep_opts_t.tap_begin/tap_end)."""
@@ -245,7 +248,7 @@ def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel,
                           chunk_nnz=2048 * (1 if int(wl.get("blocks", world)) == 1 else 4))
     eng = ALSEngine(csr_u, csr_i, X, Y, wl["lamb"], wl["alpha"], ub, ib, group, solver=solver,
                     cg_steps=cg_steps, cg_form=cg_form, short_rows={"auto": "auto", "on": True, "off": False}[short_rows]
-                    if solver != "cg" else False, stream_reserve_cus=reserve_cus,
+                    if solver != "cg" else False, stream_reserve_cus=reserve_cus, overlap_chunks=overlap_chunks,
                     **({} if gap_ticks is None else {"exchange_gap_ticks": gap_ticks}))
     short = dict(eng.short)
     cg = solver == "cg"
@@ -678,7 +681,7 @@ def main():
     head, shards, (Xh, Yh, wl) = measure(ctx, args.workload, args.factors, args.solver, args.cg_steps, args.cg_form,
                                          args.accumulate, args.row_kernel, args.steps, args.warmup,
                                          short_rows=args.short_rows, reserve_cus=args.reserve_cus, gap_ticks=args.gap_ticks,
-                                         tap_every=max(1, args.tap_every))
+                                         tap_every=max(1, args.tap_every), overlap_chunks=args.overlap_chunks)
     f = head["f"]
     cg = head["solver"] == "cg"
 
