@@ -241,11 +241,10 @@ def measure(ctx, workload, f, solver, cg_steps, cg_form, accumulate, row_kernel,
     if cg_steps is None:
         from recommender_amd.als import default_cg_steps
         cg_steps = default_cg_steps(f)
-    csr_u = ops.DeviceCSR(U[0], U[1], U[2], (ub[rank + 1] - ub[rank], M), dev)
-    # with N user blocks an item row is N times longer: longer chunks keep the partial-sum traffic of the
-    # split rows (11 KB per chunk at f=64) small against the gather
-    csr_i = ops.DeviceCSR(Ut[0], Ut[1], Ut[2], (ib[rank + 1] - ib[rank], N), dev,
-                          chunk_nnz=2048 * (1 if int(wl.get("blocks", world)) == 1 else 4))
+    # entries per chunk item of a long row: the library's choice for this f (ALS_BENCH_CHUNK_NNZ: experiments)
+    base_chunk = int(os.environ.get("ALS_BENCH_CHUNK_NNZ", "0")) or ops.default_chunk_nnz(f)
+    csr_u = ops.DeviceCSR(U[0], U[1], U[2], (ub[rank + 1] - ub[rank], M), dev, chunk_nnz=base_chunk)
+    csr_i = ops.DeviceCSR(Ut[0], Ut[1], Ut[2], (ib[rank + 1] - ib[rank], N), dev, chunk_nnz=base_chunk)
     eng = ALSEngine(csr_u, csr_i, X, Y, wl["lamb"], wl["alpha"], ub, ib, group, solver=solver,
                     cg_steps=cg_steps, cg_form=cg_form, short_rows={"auto": "auto", "on": True, "off": False}[short_rows]
                     if solver != "cg" else False, stream_reserve_cus=reserve_cus, overlap_chunks=overlap_chunks,
@@ -538,8 +537,8 @@ def measure_rank_share(ctx, wl_name, solver, cg_steps, accumulate, row_kernel, s
         Ut = data.csr_from_sorted_keys(tk, tr, mi, N)
         del tk, tr
         torch.cuda.empty_cache()
-        state = (ops.DeviceCSR(U[0], U[1], U[2], (nb, M), dev),
-                 ops.DeviceCSR(Ut[0], Ut[1], Ut[2], (mi, N), dev, chunk_nnz=2048 * 4))
+        state = (ops.DeviceCSR(U[0], U[1], U[2], (nb, M), dev, chunk_nnz=ops.default_chunk_nnz(f)),
+                 ops.DeviceCSR(Ut[0], Ut[1], Ut[2], (mi, N), dev, chunk_nnz=ops.default_chunk_nnz(f)))
     csr_u, csr_i = state
     g = torch.Generator(device=dev); g.manual_seed(42)
     X = torch.randn((N, f), generator=g, device=dev) / np.sqrt(f)

@@ -29,7 +29,7 @@ DEFAULTS = dict(f=20,           # ALS.json.template:26 (the reference's layer wi
                 seed=42,
                 phantom_rows=0,     # >0: TensorFlow-path layout, layers get extra never-updated rows
                                     # that still enter the Gram (ALS.py:243, ALS.py:456)
-                chunk_nnz=2048,
+                chunk_nnz=None,     # entries per chunk item of a long row; None = ops.default_chunk_nnz(f)
                 solver="auto",      # "cholesky" (exact, f <= 128), "cg", or "auto" = exact where it exists
                 cg_steps=None,      # conjugate-gradient steps per row and half-sweep when solver is "cg"; None =
                                     # als.default_cg_steps(f) = max(10, ceil(f / 6)), the count at which 15 iterations
@@ -119,10 +119,14 @@ class RecommenderALS:
             raise RuntimeError("call input_data() first")
         self._ensure_factors()
         c = self.config
-        cu = ops.DeviceCSR.from_scipy(self.Utrain, self.device, c["chunk_nnz"])
+        cu = ops.DeviceCSR.from_scipy(self.Utrain, self.device, self._chunk_nnz())
         ci = cu.transpose()             # on the device (the reference transposes on the host, ALS.py:432)
         self.engine = ALSEngine(cu, ci, self.X, self.Y, c["lamb"], c["alpha"], solver=c["solver"],
                                 cg_steps=c["cg_steps"], short_rows=c["short_rows"])
+
+    def _chunk_nnz(self):
+        c = self.config["chunk_nnz"]
+        return ops.default_chunk_nnz(self.config["f"]) if c is None else int(c)
 
     # ------------------------------------------------------------------ training
     def train(self, epochs=None, evaluate=None):
@@ -287,7 +291,7 @@ class RecommenderALS:
         uniq, inv = np.unique(rows, return_inverse=True)
         U = sps.csr_matrix((vals, (inv, cols)), shape=(len(uniq), self.n_items))   # duplicates sum, as csr_matrix does
         U.sort_indices()
-        return ops.DeviceCSR.from_scipy(U, self.device, self.config["chunk_nnz"], row_ids=uniq)
+        return ops.DeviceCSR.from_scipy(U, self.device, self._chunk_nnz(), row_ids=uniq)
 
     def update_user(self, rows, cols=None, vals=None, refresh_gram=True):
         """Fold-in (ALSUpdateAlgo.update_user, ALS.py:375-385): re-solves the factor rows of the given users from
