@@ -97,10 +97,10 @@ def default_chunk_nnz(f):
     chunk items whose partial sums a second kernel combines; the longer the chunks, the fewer partial sums - but a whole
     row is one wavefront's work, and one that outlasts the rest of the launch holds it up.  Measured on the 25 M-entry
     matrix (162 541 x 59 047; per iteration, chunk 2048 / 8192 / 16384 / 32768): f = 64 2.08 / 1.99 / 1.96 / 2.24 ms,
-    f = 128 6.86 / 6.6 / 7.05 / 9.7 ms.  The value depends on f alone - never on the matrix or a rank's shard of it - so
+    f = 128 6.86 / 6.6 / 7.05 / 9.7 ms; the lock-step conjugate-gradient form of f > 128 gains 1 % from 8192.  The value depends on f alone - never on the matrix or a rank's shard of it - so
     that every shard of a distributed run is cut like the whole (a row's bits depend on its chunking)."""
     f = int(f)
-    return 16384 if f <= 64 else 8192 if f <= _lib.MAX_FACTORS_EXACT else _lib.DEFAULT_CHUNK_NNZ
+    return 16384 if f <= 64 else 8192
 
 
 def build_plan(indptr, chunk_nnz=_lib.DEFAULT_CHUNK_NNZ):
