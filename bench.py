@@ -80,7 +80,7 @@ def parse():
                     help="the per-row kernels of every n-th timed step are bracketed by events (launch durations of the roofline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="only the headline measurement")
-    ap.add_argument("--also-steps", type=int, default=3)
+    ap.add_argument("--also-steps", type=int, default=5)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work per half-sweep sample")
     return ap.parse_args()
 
@@ -699,7 +699,7 @@ def main():
         for (wname, ff, solver, sh, cgs) in plan:
             try:
                 r, prev, _ = measure(ctx, wname, ff, solver, cgs if cgs > 0 else args.cg_steps, "auto", args.accumulate, args.row_kernel,
-                                     args.also_steps, 1, shards=prev if sh == "prev" else sh, short_rows=args.short_rows,
+                                     args.also_steps, 2, shards=prev if sh == "prev" else sh, short_rows=args.short_rows,
                                      reserve_cus=args.reserve_cus, gap_ticks=args.gap_ticks)
                 also.append({"workload": r["workload"], "f": r["f"], "solver": r["solver"], "cg_steps": r["cg_steps"],
                              "steps": r["steps"],
@@ -728,7 +728,7 @@ def main():
             for (solver, cgs) in (("cholesky", 0), ("cg", args.cg_steps)):        # None: the default count for f
                 try:
                     r, state = measure_rank_share(ctx, "c3_rank_syn", solver, cgs, args.accumulate, args.row_kernel,
-                                                  args.also_steps, 1, state, short_rows=args.short_rows)
+                                                  args.also_steps, 2, state, short_rows=args.short_rows)
                     also.append(r)
                 except Exception as exc:
                     also.append({"workload": "c3_rank_syn", "solver": solver, "error": repr(exc)})
